@@ -1,0 +1,336 @@
+"""adacodec — MI355X-native succinct column-segment codec (host-side Python binding of libadacodec.so).
+
+The product is the C-ABI shared library built from csrc/ (include/adacodec.h); this module is the thin
+ctypes binding used by the tests, bench.py and __graft_entry__.py.  It never computes anything itself and
+has NO CPU fallback: if the HIP extension is missing or no gfx950 device is usable, calls raise AdacError.
+
+Import with importlib (the directory name is not a Python identifier):
+    adac = importlib.import_module("duckdb-adaptive-compression_amd")
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libadacodec.so")
+
+# adac_type == duckdb::PhysicalType codes
+UINT8, INT8, UINT16, INT16, UINT32, INT32, UINT64, INT64 = 2, 3, 4, 5, 6, 7, 8, 9
+RULE_APPEND, RULE_RECOMPACT = 0, 1
+NO_MIN = 0xFFFFFFFFFFFFFFFF
+SEG_PACKED = 1
+
+_NP2TYPE = {
+    np.dtype(np.uint8): UINT8, np.dtype(np.int8): INT8, np.dtype(np.uint16): UINT16, np.dtype(np.int16): INT16,
+    np.dtype(np.uint32): UINT32, np.dtype(np.int32): INT32, np.dtype(np.uint64): UINT64, np.dtype(np.int64): INT64,
+}
+_TYPE2NP = {v: k for k, v in _NP2TYPE.items()}
+
+STATUS_NAMES = {0: "OK", 1: "INVALID_ARGUMENT", 2: "UNSUPPORTED_TYPE", 3: "DEVICE", 4: "OUT_OF_MEMORY", 5: "NO_DEVICE"}
+
+SEGMENT_DESC_DTYPE = np.dtype([
+    ("word_off", np.uint64), ("val_off", np.uint64), ("min", np.uint64), ("count", np.uint32),
+    ("width", np.uint8), ("flags", np.uint8), ("reserved", np.uint16),
+])
+assert SEGMENT_DESC_DTYPE.itemsize == 32
+
+
+class AdacError(RuntimeError):
+    def __init__(self, status, where):
+        self.status = status
+        detail = ""
+        try:
+            detail = lib().adac_last_error().decode() if status == 3 else ""
+        except Exception:  # pragma: no cover
+            pass
+        super().__init__("%s failed: ADAC_ERR_%s %s" % (where, STATUS_NAMES.get(status, status), detail))
+
+
+def physical_type(dtype):
+    try:
+        return _NP2TYPE[np.dtype(dtype)]
+    except (KeyError, TypeError):
+        raise AdacError(2, "physical_type(%r)" % (dtype,))
+
+
+def numpy_dtype(ptype):
+    return _TYPE2NP[ptype]
+
+
+def build(force=False):
+    """Compile libadacodec.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "adacodec.h"))
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "all"])
+    return LIB_PATH
+
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol include/adacodec.h declares
+_u64, _u32, _u8, _int, _vp, _sz = C.c_uint64, C.c_uint32, C.c_uint8, C.c_int, C.c_void_p, C.c_size_t
+_P = C.POINTER
+SIGNATURES = {
+    "adac_abi_version": (_int, []),
+    "adac_status_string": (C.c_char_p, [_int]),
+    "adac_last_error": (C.c_char_p, []),
+    "adac_type_is_supported": (_int, [_int]),
+    "adac_type_size": (_u32, [_int]),
+    "adac_hi": (_u32, [_u64]),
+    "adac_width": (_u8, [_u64, _u64, _int, _int]),
+    "adac_packed_words": (_u64, [_u64, _u8]),
+    "adac_size_in_bytes": (_u64, [_u64, _u8]),
+    "adac_arena_words": (_u64, [_u64, _u8]),
+    "adac_tile_values": (_u32, [_int]),
+    "adac_ctx_create": (_int, [_int, _vp, _P(_vp)]),
+    "adac_ctx_destroy": (None, [_vp]),
+    "adac_ctx_sync": (_int, [_vp]),
+    "adac_ctx_stream": (_vp, [_vp]),
+    "adac_ctx_device": (_int, [_vp]),
+    "adac_dev_alloc": (_int, [_vp, _sz, _P(_vp)]),
+    "adac_dev_free": (_int, [_vp, _vp]),
+    "adac_dev_memset": (_int, [_vp, _vp, _int, _sz]),
+    "adac_memcpy_h2d": (_int, [_vp, _vp, _vp, _sz]),
+    "adac_memcpy_d2h": (_int, [_vp, _vp, _vp, _sz]),
+    "adac_timer_start": (_int, [_vp]),
+    "adac_timer_stop": (_int, [_vp, _P(C.c_float)]),
+    "adac_layout_create": (_int, [_vp, _int, _vp, _vp, _u64, _P(_vp)]),
+    "adac_layout_destroy": (None, [_vp]),
+    "adac_layout_nseg": (_u64, [_vp]),
+    "adac_layout_ntiles": (_u64, [_vp]),
+    "adac_layout_total_values": (_u64, [_vp]),
+    "adac_layout_value_span": (_u64, [_vp]),
+    "adac_layout_max_arena_words": (_u64, [_vp]),
+    "adac_layout_set_descs": (_int, [_vp, _vp]),
+    "adac_layout_get_descs": (_int, [_vp, _vp]),
+    "adac_layout_get_minmax": (_int, [_vp, _vp]),
+    "adac_layout_device_descs": (_vp, [_vp]),
+    "adac_analyze": (_int, [_vp, _vp, _vp, _int]),
+    "adac_plan": (_int, [_vp, _int, _int]),
+    "adac_pack": (_int, [_vp, _vp, _vp, _vp]),
+    "adac_encode": (_int, [_vp, _vp, _vp, _int, _int, _vp]),
+    "adac_unpack": (_int, [_vp, _vp, _vp]),
+    "adac_unpack_range": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _u64]),
+    "adac_fetch_rows": (_int, [_vp, _vp, _vp, _vp, _u64, _vp]),
+    "adac_scan_sum": (_int, [_vp, _vp, _vp]),
+    "adac_scan_count_eq": (_int, [_vp, _vp, _u64, _vp]),
+}
+
+
+def lib():
+    """Load libadacodec.so; fail loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AdacError(5, "load %s (HIP extension not built: run __graft_entry__.build())" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(st, where):
+    if st != 0:
+        raise AdacError(st, where)
+
+
+def _dptr(x):
+    """Device pointer of a torch tensor / DeviceBuffer / int / None."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    if hasattr(x, "ptr"):
+        return x.ptr
+    raise TypeError("not a device buffer: %r" % (x,))
+
+
+# host-only helpers -------------------------------------------------------------------------------
+
+def width(mn, mx, rule=RULE_APPEND, pad_to_byte=False):
+    return lib().adac_width(mn & NO_MIN, mx & NO_MIN, rule, int(pad_to_byte))
+
+
+def size_in_bytes(count, w):
+    return lib().adac_size_in_bytes(count, w)
+
+
+def packed_words(count, w):
+    return lib().adac_packed_words(count, w)
+
+
+def arena_words(count, w):
+    return lib().adac_arena_words(count, w)
+
+
+def tile_values(dtype):
+    return lib().adac_tile_values(physical_type(dtype))
+
+
+class DeviceBuffer:
+    """hipMalloc'd buffer owned through the C ABI (for hosts that have no torch)."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        self.nbytes = nbytes
+        p = _vp()
+        _check(lib().adac_dev_alloc(ctx._h, nbytes, C.byref(p)), "adac_dev_alloc")
+        self.ptr = p.value
+
+    def free(self):
+        if self.ptr:
+            lib().adac_dev_free(self.ctx._h, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # pragma: no cover
+            pass
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        _check(lib().adac_memcpy_h2d(self.ctx._h, self.ptr, arr.ctypes.data, arr.nbytes), "adac_memcpy_h2d")
+        return self
+
+    def download(self, dtype, count, byte_offset=0):
+        out = np.empty(count, dtype=dtype)
+        assert byte_offset + out.nbytes <= self.nbytes
+        _check(lib().adac_memcpy_d2h(self.ctx._h, out.ctypes.data, self.ptr + byte_offset, out.nbytes),
+               "adac_memcpy_d2h")
+        return out
+
+    def zero(self):
+        _check(lib().adac_dev_memset(self.ctx._h, self.ptr, 0, self.nbytes), "adac_dev_memset")
+        return self
+
+
+class Context:
+    def __init__(self, device=0, stream=None):
+        h = _vp()
+        _check(lib().adac_ctx_create(device, stream, C.byref(h)), "adac_ctx_create")
+        self._h = h.value
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().adac_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pragma: no cover
+            pass
+
+    def sync(self):
+        _check(lib().adac_ctx_sync(self._h), "adac_ctx_sync")
+
+    @property
+    def stream(self):
+        return lib().adac_ctx_stream(self._h)
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        return DeviceBuffer(self, max(arr.nbytes, 16)).upload(arr)
+
+    def timer_start(self):
+        _check(lib().adac_timer_start(self._h), "adac_timer_start")
+
+    def timer_stop(self):
+        ms = C.c_float()
+        _check(lib().adac_timer_stop(self._h, C.byref(ms)), "adac_timer_stop")
+        return ms.value
+
+
+class Layout:
+    """A batch of column segments of one type on one device (adac_layout)."""
+
+    def __init__(self, ctx, dtype, counts, val_offs=None):
+        self.ctx = ctx
+        self.dtype = np.dtype(dtype)
+        self.ptype = physical_type(dtype)
+        self.counts = np.ascontiguousarray(counts, dtype=np.uint32)
+        offs = None if val_offs is None else np.ascontiguousarray(val_offs, dtype=np.uint64)
+        h = _vp()
+        _check(lib().adac_layout_create(ctx._h, self.ptype, self.counts.ctypes.data,
+                                        None if offs is None else offs.ctypes.data, len(self.counts), C.byref(h)),
+               "adac_layout_create")
+        self._h = h.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().adac_layout_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pragma: no cover
+            pass
+
+    nseg = property(lambda s: lib().adac_layout_nseg(s._h))
+    ntiles = property(lambda s: lib().adac_layout_ntiles(s._h))
+    total_values = property(lambda s: lib().adac_layout_total_values(s._h))
+    value_span = property(lambda s: lib().adac_layout_value_span(s._h))
+    max_arena_words = property(lambda s: lib().adac_layout_max_arena_words(s._h))
+
+    def set_descs(self, descs):
+        descs = np.ascontiguousarray(descs, dtype=SEGMENT_DESC_DTYPE)
+        _check(lib().adac_layout_set_descs(self._h, descs.ctypes.data), "adac_layout_set_descs")
+
+    def get_descs(self):
+        descs = np.zeros(self.nseg, dtype=SEGMENT_DESC_DTYPE)
+        _check(lib().adac_layout_get_descs(self._h, descs.ctypes.data), "adac_layout_get_descs")
+        return descs
+
+    def get_minmax(self):
+        mm = np.zeros((self.nseg, 2), dtype=np.uint64)
+        _check(lib().adac_layout_get_minmax(self._h, mm.ctypes.data), "adac_layout_get_minmax")
+        return mm
+
+    def analyze(self, d_vals, d_validity=None, rule=RULE_APPEND):
+        _check(lib().adac_analyze(self._h, _dptr(d_vals), _dptr(d_validity), rule), "adac_analyze")
+
+    def plan(self, rule=RULE_APPEND, pad_to_byte=False):
+        _check(lib().adac_plan(self._h, rule, int(pad_to_byte)), "adac_plan")
+
+    def pack(self, d_vals, d_words, d_validity=None):
+        _check(lib().adac_pack(self._h, _dptr(d_vals), _dptr(d_validity), _dptr(d_words)), "adac_pack")
+
+    def encode(self, d_vals, d_words, d_validity=None, rule=RULE_APPEND, pad_to_byte=False):
+        _check(lib().adac_encode(self._h, _dptr(d_vals), _dptr(d_validity), rule, int(pad_to_byte), _dptr(d_words)),
+               "adac_encode")
+
+    def unpack(self, d_words, d_out):
+        _check(lib().adac_unpack(self._h, _dptr(d_words), _dptr(d_out)), "adac_unpack")
+
+    def unpack_range(self, d_words, seg, start, count, d_out, out_off=0):
+        _check(lib().adac_unpack_range(self._h, _dptr(d_words), seg, start, count, _dptr(d_out), out_off),
+               "adac_unpack_range")
+
+    def fetch_rows(self, d_words, d_segs, d_rows, n, d_out):
+        _check(lib().adac_fetch_rows(self._h, _dptr(d_words), _dptr(d_segs), _dptr(d_rows), n, _dptr(d_out)),
+               "adac_fetch_rows")
+
+    def scan_sum(self, d_words, d_sums):
+        _check(lib().adac_scan_sum(self._h, _dptr(d_words), _dptr(d_sums)), "adac_scan_sum")
+
+    def scan_count_eq(self, d_words, key, d_counts):
+        _check(lib().adac_scan_count_eq(self._h, _dptr(d_words), key & NO_MIN, _dptr(d_counts)), "adac_scan_count_eq")
+
+
+from .layout import appender_segment_counts, aligned_value_offsets  # noqa: E402,F401

@@ -1,0 +1,432 @@
+// adac_capi.cpp — the C ABI of libadacodec (include/adacodec.h): contexts, layouts (tile tables and
+// descriptor tables in HBM) and the enqueue functions of the hot path.  Host logic only; the arithmetic
+// lives in adac_kernels.hip.  There is deliberately no CPU implementation behind any device entry point.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "adac_internal.h"
+#include "adacodec.h"
+
+using adac::RangeArgs;
+using adac::TileRef;
+
+static thread_local std::string g_last_error;
+
+static adac_status fail_hip(hipError_t e, const char *what) {
+	g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+	if (e == hipErrorOutOfMemory) return ADAC_ERR_OUT_OF_MEMORY;
+	if (e == hipErrorNoDevice || e == hipErrorInvalidDevice) return ADAC_ERR_NO_DEVICE;
+	return ADAC_ERR_DEVICE;
+}
+
+#define ADAC_HIP(expr)                                                                                                 \
+	do {                                                                                                               \
+		hipError_t _e = (expr);                                                                                        \
+		if (_e != hipSuccess) return fail_hip(_e, #expr);                                                              \
+	} while (0)
+
+struct adac_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	bool owns_stream = false;
+	hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+};
+
+struct adac_layout {
+	adac_ctx *ctx = nullptr;
+	int type = 0;
+	uint32_t type_size = 0;
+	bool is_signed = false;
+	uint64_t null_bits = 0; // NullValue<T>() as the bit pattern of T, zero-extended (null_value.hpp:26-28)
+	uint64_t nseg = 0, ntiles = 0, total_values = 0, value_span = 0, max_arena_words = 0;
+	std::vector<uint32_t> counts;
+	std::vector<uint64_t> val_offs;
+	adac_segment_desc *d_descs = nullptr;
+	TileRef *d_tiles = nullptr;
+	uint64_t *d_minmax = nullptr;
+};
+
+// ------------------------------------------------------------------------------------------------
+// host-only helpers
+// ------------------------------------------------------------------------------------------------
+
+extern "C" int adac_abi_version(void) { return ADAC_ABI_VERSION; }
+
+extern "C" const char *adac_status_string(adac_status s) {
+	switch (s) {
+	case ADAC_OK: return "ok";
+	case ADAC_ERR_INVALID_ARGUMENT: return "invalid argument";
+	case ADAC_ERR_UNSUPPORTED_TYPE: return "unsupported physical type for the succinct codec";
+	case ADAC_ERR_DEVICE: return "HIP device error";
+	case ADAC_ERR_OUT_OF_MEMORY: return "out of device memory";
+	case ADAC_ERR_NO_DEVICE: return "no usable gfx950 device";
+	}
+	return "unknown status";
+}
+
+extern "C" const char *adac_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int adac_type_is_supported(int t) { return t >= ADAC_UINT8 && t <= ADAC_INT64; }
+
+extern "C" uint32_t adac_type_size(int t) {
+	switch (t) {
+	case ADAC_UINT8:
+	case ADAC_INT8: return 1;
+	case ADAC_UINT16:
+	case ADAC_INT16: return 2;
+	case ADAC_UINT32:
+	case ADAC_INT32: return 4;
+	case ADAC_UINT64:
+	case ADAC_INT64: return 8;
+	default: return 0;
+	}
+}
+
+static bool type_is_signed(int t) { return t == ADAC_INT8 || t == ADAC_INT16 || t == ADAC_INT32 || t == ADAC_INT64; }
+
+extern "C" uint32_t adac_hi(uint64_t x) { return x == 0 ? 0u : 63u - (uint32_t)__builtin_clzll(x); }
+
+extern "C" uint8_t adac_width(uint64_t mn, uint64_t mx, int rule, int pad_to_byte) {
+	uint32_t w;
+	if (rule == ADAC_RULE_APPEND) {
+		w = adac_hi(mx - mn) + 1;
+	} else {
+		if (mx != 0 && mn != UINT64_MAX && mx > mn) mx -= mn;
+		w = adac_hi(mx) + 1;
+	}
+	if (pad_to_byte) w = (w + 7u) & ~7u;
+	return (uint8_t)w;
+}
+
+extern "C" uint64_t adac_packed_words(uint64_t count, uint8_t width) { return (count * width + 63) >> 6; }
+
+extern "C" uint64_t adac_size_in_bytes(uint64_t count, uint8_t width) { return 9 + (adac_packed_words(count, width) << 3); }
+
+extern "C" uint64_t adac_arena_words(uint64_t count, uint8_t width) {
+	return (((count * width + 64) >> 6) + 15) & ~15ull;
+}
+
+extern "C" uint32_t adac_tile_values(int t) {
+	uint32_t ts = adac_type_size(t);
+	return ts ? adac::tile_values(ts) : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+
+extern "C" adac_status adac_ctx_create(int device, void *external_stream, adac_ctx **out) {
+	if (!out) return ADAC_ERR_INVALID_ARGUMENT;
+	*out = nullptr;
+	int ndev = 0;
+	hipError_t e = hipGetDeviceCount(&ndev);
+	if (e != hipSuccess || ndev == 0) {
+		g_last_error = "hipGetDeviceCount: no HIP device";
+		return ADAC_ERR_NO_DEVICE;
+	}
+	if (device < 0 || device >= ndev) return ADAC_ERR_INVALID_ARGUMENT;
+	ADAC_HIP(hipSetDevice(device));
+	adac_ctx *c = new (std::nothrow) adac_ctx();
+	if (!c) return ADAC_ERR_OUT_OF_MEMORY;
+	c->device = device;
+	if (external_stream) {
+		c->stream = static_cast<hipStream_t>(external_stream);
+	} else {
+		e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+		if (e != hipSuccess) {
+			delete c;
+			return fail_hip(e, "hipStreamCreateWithFlags");
+		}
+		c->owns_stream = true;
+	}
+	hipEventCreate(&c->ev_start);
+	hipEventCreate(&c->ev_stop);
+	*out = c;
+	return ADAC_OK;
+}
+
+extern "C" void adac_ctx_destroy(adac_ctx *c) {
+	if (!c) return;
+	hipSetDevice(c->device);
+	if (c->ev_start) hipEventDestroy(c->ev_start);
+	if (c->ev_stop) hipEventDestroy(c->ev_stop);
+	if (c->owns_stream && c->stream) hipStreamDestroy(c->stream);
+	delete c;
+}
+
+extern "C" adac_status adac_ctx_sync(adac_ctx *c) {
+	if (!c) return ADAC_ERR_INVALID_ARGUMENT;
+	ADAC_HIP(hipSetDevice(c->device));
+	ADAC_HIP(hipStreamSynchronize(c->stream));
+	return ADAC_OK;
+}
+
+extern "C" void *adac_ctx_stream(adac_ctx *c) { return c ? c->stream : nullptr; }
+extern "C" int adac_ctx_device(adac_ctx *c) { return c ? c->device : -1; }
+
+extern "C" adac_status adac_dev_alloc(adac_ctx *c, size_t bytes, void **d_ptr) {
+	if (!c || !d_ptr) return ADAC_ERR_INVALID_ARGUMENT;
+	ADAC_HIP(hipSetDevice(c->device));
+	ADAC_HIP(hipMalloc(d_ptr, bytes ? bytes : 16));
+	return ADAC_OK;
+}
+
+extern "C" adac_status adac_dev_free(adac_ctx *c, void *d_ptr) {
+	if (!c) return ADAC_ERR_INVALID_ARGUMENT;
+	if (!d_ptr) return ADAC_OK;
+	ADAC_HIP(hipSetDevice(c->device));
+	ADAC_HIP(hipFree(d_ptr));
+	return ADAC_OK;
+}
+
+extern "C" adac_status adac_dev_memset(adac_ctx *c, void *d_ptr, int byte, size_t bytes) {
+	if (!c || (!d_ptr && bytes)) return ADAC_ERR_INVALID_ARGUMENT;
+	if (!bytes) return ADAC_OK;
+	ADAC_HIP(hipSetDevice(c->device));
+	ADAC_HIP(hipMemsetAsync(d_ptr, byte, bytes, c->stream));
+	return ADAC_OK;
+}
+
+extern "C" adac_status adac_memcpy_h2d(adac_ctx *c, void *d_dst, const void *src, size_t bytes) {
+	if (!c || ((!d_dst || !src) && bytes)) return ADAC_ERR_INVALID_ARGUMENT;
+	if (!bytes) return ADAC_OK;
+	ADAC_HIP(hipSetDevice(c->device));
+	ADAC_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+	ADAC_HIP(hipStreamSynchronize(c->stream));
+	return ADAC_OK;
+}
+
+extern "C" adac_status adac_memcpy_d2h(adac_ctx *c, void *dst, const void *d_src, size_t bytes) {
+	if (!c || ((!dst || !d_src) && bytes)) return ADAC_ERR_INVALID_ARGUMENT;
+	if (!bytes) return ADAC_OK;
+	ADAC_HIP(hipSetDevice(c->device));
+	ADAC_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+	ADAC_HIP(hipStreamSynchronize(c->stream));
+	return ADAC_OK;
+}
+
+extern "C" adac_status adac_timer_start(adac_ctx *c) {
+	if (!c) return ADAC_ERR_INVALID_ARGUMENT;
+	ADAC_HIP(hipSetDevice(c->device));
+	ADAC_HIP(hipEventRecord(c->ev_start, c->stream));
+	return ADAC_OK;
+}
+
+extern "C" adac_status adac_timer_stop(adac_ctx *c, float *ms) {
+	if (!c || !ms) return ADAC_ERR_INVALID_ARGUMENT;
+	ADAC_HIP(hipSetDevice(c->device));
+	ADAC_HIP(hipEventRecord(c->ev_stop, c->stream));
+	ADAC_HIP(hipEventSynchronize(c->ev_stop));
+	ADAC_HIP(hipEventElapsedTime(ms, c->ev_start, c->ev_stop));
+	return ADAC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout
+// ------------------------------------------------------------------------------------------------
+
+extern "C" adac_status adac_layout_create(adac_ctx *c, int type, const uint32_t *counts, const uint64_t *val_offs,
+                                          uint64_t nseg, adac_layout **out) {
+	if (!c || !out || (nseg && !counts)) return ADAC_ERR_INVALID_ARGUMENT;
+	*out = nullptr;
+	if (!adac_type_is_supported(type)) return ADAC_ERR_UNSUPPORTED_TYPE;
+	if (nseg >= 0xffffffffull) return ADAC_ERR_INVALID_ARGUMENT;
+	adac_layout *l = new (std::nothrow) adac_layout();
+	if (!l) return ADAC_ERR_OUT_OF_MEMORY;
+	l->ctx = c;
+	l->type = type;
+	l->type_size = adac_type_size(type);
+	l->is_signed = type_is_signed(type);
+	l->null_bits = l->is_signed ? (1ull << (8 * l->type_size - 1)) : 0ull;
+	l->nseg = nseg;
+	l->counts.assign(counts, counts + nseg);
+	l->val_offs.resize(nseg);
+	const uint32_t tile = adac::tile_values(l->type_size);
+	const uint8_t full_w = (uint8_t)(8 * l->type_size);
+	std::vector<adac_segment_desc> descs(nseg);
+	std::vector<TileRef> tiles;
+	uint64_t run = 0, arena = 0;
+	for (uint64_t s = 0; s < nseg; s++) {
+		const uint64_t off = val_offs ? val_offs[s] : run;
+		l->val_offs[s] = off;
+		run = off + counts[s];
+		if (off + counts[s] > l->value_span) l->value_span = off + counts[s];
+		l->total_values += counts[s];
+		adac_segment_desc &d = descs[s];
+		d.word_off = arena;
+		d.val_off = off;
+		d.min = ADAC_NO_MIN;
+		d.count = counts[s];
+		d.width = full_w;
+		d.flags = 0;
+		d.reserved = 0;
+		arena += adac_arena_words(counts[s], full_w);
+		for (uint64_t first = 0; first < counts[s]; first += tile) {
+			tiles.push_back(TileRef {(uint32_t)s, (uint32_t)first});
+		}
+	}
+	l->max_arena_words = arena;
+	l->ntiles = tiles.size();
+	if (l->ntiles >= 0x7fffffffull) { // grid.x limit
+		delete l;
+		return ADAC_ERR_INVALID_ARGUMENT;
+	}
+	hipError_t e = hipSetDevice(c->device);
+	if (e == hipSuccess) e = hipMalloc((void **)&l->d_descs, (nseg ? nseg : 1) * sizeof(adac_segment_desc));
+	if (e == hipSuccess) e = hipMalloc((void **)&l->d_tiles, (l->ntiles ? l->ntiles : 1) * sizeof(TileRef));
+	if (e == hipSuccess) e = hipMalloc((void **)&l->d_minmax, (nseg ? nseg : 1) * 2 * sizeof(uint64_t));
+	if (e == hipSuccess && nseg)
+		e = hipMemcpyAsync(l->d_descs, descs.data(), nseg * sizeof(adac_segment_desc), hipMemcpyHostToDevice, c->stream);
+	if (e == hipSuccess && l->ntiles)
+		e = hipMemcpyAsync(l->d_tiles, tiles.data(), l->ntiles * sizeof(TileRef), hipMemcpyHostToDevice, c->stream);
+	if (e == hipSuccess) e = adac::launch_minmax_init(c->stream, l->d_minmax, nseg);
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream); // descs/tiles are stack-local
+	if (e != hipSuccess) {
+		adac_status st = fail_hip(e, "adac_layout_create");
+		adac_layout_destroy(l);
+		return st;
+	}
+	*out = l;
+	return ADAC_OK;
+}
+
+extern "C" void adac_layout_destroy(adac_layout *l) {
+	if (!l) return;
+	hipSetDevice(l->ctx->device);
+	if (l->d_descs) hipFree(l->d_descs);
+	if (l->d_tiles) hipFree(l->d_tiles);
+	if (l->d_minmax) hipFree(l->d_minmax);
+	delete l;
+}
+
+extern "C" uint64_t adac_layout_nseg(const adac_layout *l) { return l ? l->nseg : 0; }
+extern "C" uint64_t adac_layout_ntiles(const adac_layout *l) { return l ? l->ntiles : 0; }
+extern "C" uint64_t adac_layout_total_values(const adac_layout *l) { return l ? l->total_values : 0; }
+extern "C" uint64_t adac_layout_value_span(const adac_layout *l) { return l ? l->value_span : 0; }
+extern "C" uint64_t adac_layout_max_arena_words(const adac_layout *l) { return l ? l->max_arena_words : 0; }
+extern "C" const adac_segment_desc *adac_layout_device_descs(const adac_layout *l) { return l ? l->d_descs : nullptr; }
+
+extern "C" adac_status adac_layout_set_descs(adac_layout *l, const adac_segment_desc *descs) {
+	if (!l || (l->nseg && !descs)) return ADAC_ERR_INVALID_ARGUMENT;
+	const uint32_t full_w = 8 * l->type_size;
+	for (uint64_t s = 0; s < l->nseg; s++) {
+		const adac_segment_desc &d = descs[s];
+		if (d.count != l->counts[s] || d.val_off != l->val_offs[s]) return ADAC_ERR_INVALID_ARGUMENT;
+		if (d.width == 0 || d.width > full_w || (d.word_off & 15)) return ADAC_ERR_INVALID_ARGUMENT;
+		if (!(d.flags & ADAC_SEG_PACKED) && d.width != full_w) return ADAC_ERR_INVALID_ARGUMENT;
+	}
+	ADAC_HIP(hipSetDevice(l->ctx->device));
+	if (l->nseg) {
+		ADAC_HIP(hipMemcpyAsync(l->d_descs, descs, l->nseg * sizeof(adac_segment_desc), hipMemcpyHostToDevice,
+		                        l->ctx->stream));
+		ADAC_HIP(hipStreamSynchronize(l->ctx->stream));
+	}
+	return ADAC_OK;
+}
+
+extern "C" adac_status adac_layout_get_descs(adac_layout *l, adac_segment_desc *descs) {
+	if (!l || (l->nseg && !descs)) return ADAC_ERR_INVALID_ARGUMENT;
+	return adac_memcpy_d2h(l->ctx, descs, l->d_descs, l->nseg * sizeof(adac_segment_desc));
+}
+
+extern "C" adac_status adac_layout_get_minmax(adac_layout *l, uint64_t *minmax) {
+	if (!l || (l->nseg && !minmax)) return ADAC_ERR_INVALID_ARGUMENT;
+	return adac_memcpy_d2h(l->ctx, minmax, l->d_minmax, l->nseg * 2 * sizeof(uint64_t));
+}
+
+// ------------------------------------------------------------------------------------------------
+// hot path
+// ------------------------------------------------------------------------------------------------
+
+static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+extern "C" adac_status adac_analyze(adac_layout *l, const void *d_vals, const uint64_t *d_validity, int rule) {
+	if (!l || (!d_vals && l->total_values) || (rule != ADAC_RULE_APPEND && rule != ADAC_RULE_RECOMPACT))
+		return ADAC_ERR_INVALID_ARGUMENT;
+	if (!aligned16(d_vals)) return ADAC_ERR_INVALID_ARGUMENT;
+	ADAC_HIP(hipSetDevice(l->ctx->device));
+	ADAC_HIP(adac::launch_minmax_init(l->ctx->stream, l->d_minmax, l->nseg));
+	ADAC_HIP(adac::launch_analyze(l->ctx->stream, l->type_size, l->is_signed, l->null_bits, rule, l->d_descs,
+	                              l->d_tiles, l->ntiles, d_vals, d_validity, l->d_minmax));
+	return ADAC_OK;
+}
+
+extern "C" adac_status adac_plan(adac_layout *l, int rule, int pad_to_byte) {
+	if (!l || (rule != ADAC_RULE_APPEND && rule != ADAC_RULE_RECOMPACT)) return ADAC_ERR_INVALID_ARGUMENT;
+	ADAC_HIP(hipSetDevice(l->ctx->device));
+	ADAC_HIP(adac::launch_plan(l->ctx->stream, l->type_size, rule, pad_to_byte ? 1 : 0, l->d_descs, l->d_minmax,
+	                           l->nseg));
+	return ADAC_OK;
+}
+
+extern "C" adac_status adac_pack(adac_layout *l, const void *d_vals, const uint64_t *d_validity, uint64_t *d_words) {
+	if (!l || ((!d_vals || !d_words) && l->total_values)) return ADAC_ERR_INVALID_ARGUMENT;
+	if (!aligned16(d_vals) || !aligned16(d_words)) return ADAC_ERR_INVALID_ARGUMENT;
+	ADAC_HIP(hipSetDevice(l->ctx->device));
+	ADAC_HIP(adac::launch_pack(l->ctx->stream, l->type_size, l->null_bits, l->d_descs, l->d_tiles, l->ntiles, d_vals,
+	                           d_validity, d_words));
+	return ADAC_OK;
+}
+
+extern "C" adac_status adac_encode(adac_layout *l, const void *d_vals, const uint64_t *d_validity, int rule,
+                                   int pad_to_byte, uint64_t *d_words) {
+	adac_status st = adac_analyze(l, d_vals, d_validity, rule);
+	if (st != ADAC_OK) return st;
+	st = adac_plan(l, rule, pad_to_byte);
+	if (st != ADAC_OK) return st;
+	return adac_pack(l, d_vals, d_validity, d_words);
+}
+
+extern "C" adac_status adac_unpack(adac_layout *l, const uint64_t *d_words, void *d_out) {
+	if (!l || ((!d_words || !d_out) && l->total_values)) return ADAC_ERR_INVALID_ARGUMENT;
+	if (!aligned16(d_words) || !aligned16(d_out)) return ADAC_ERR_INVALID_ARGUMENT;
+	ADAC_HIP(hipSetDevice(l->ctx->device));
+	ADAC_HIP(adac::launch_unpack(l->ctx->stream, l->type_size, l->d_descs, l->d_tiles, l->ntiles, d_words, d_out));
+	return ADAC_OK;
+}
+
+extern "C" adac_status adac_unpack_range(adac_layout *l, const uint64_t *d_words, uint64_t seg, uint64_t start,
+                                         uint64_t count, void *d_out, uint64_t out_off) {
+	if (!l || seg >= l->nseg) return ADAC_ERR_INVALID_ARGUMENT;
+	if (start > l->counts[seg] || count > l->counts[seg] - start) return ADAC_ERR_INVALID_ARGUMENT;
+	if (count == 0) return ADAC_OK;
+	if (!d_words || !d_out || !aligned16(d_words) || !aligned16(d_out)) return ADAC_ERR_INVALID_ARGUMENT;
+	ADAC_HIP(hipSetDevice(l->ctx->device));
+	RangeArgs r {(uint32_t)seg, (uint32_t)start, (uint32_t)count, out_off};
+	ADAC_HIP(adac::launch_unpack_range(l->ctx->stream, l->type_size, l->d_descs, r, d_words, d_out));
+	return ADAC_OK;
+}
+
+extern "C" adac_status adac_fetch_rows(adac_layout *l, const uint64_t *d_words, const uint32_t *d_segs,
+                                       const uint32_t *d_rows, uint64_t n, void *d_out) {
+	if (!l) return ADAC_ERR_INVALID_ARGUMENT;
+	if (n == 0) return ADAC_OK;
+	if (!d_words || !d_segs || !d_rows || !d_out) return ADAC_ERR_INVALID_ARGUMENT;
+	ADAC_HIP(hipSetDevice(l->ctx->device));
+	ADAC_HIP(adac::launch_fetch(l->ctx->stream, l->type_size, l->d_descs, d_words, d_segs, d_rows, n, d_out));
+	return ADAC_OK;
+}
+
+extern "C" adac_status adac_scan_sum(adac_layout *l, const uint64_t *d_words, uint64_t *d_sums) {
+	if (!l || (l->nseg && !d_sums) || (l->total_values && !d_words)) return ADAC_ERR_INVALID_ARGUMENT;
+	if (!aligned16(d_words)) return ADAC_ERR_INVALID_ARGUMENT;
+	ADAC_HIP(hipSetDevice(l->ctx->device));
+	if (l->nseg) ADAC_HIP(hipMemsetAsync(d_sums, 0, l->nseg * sizeof(uint64_t), l->ctx->stream));
+	ADAC_HIP(adac::launch_scan_sum(l->ctx->stream, l->type_size, l->d_descs, l->d_tiles, l->ntiles, d_words, d_sums));
+	return ADAC_OK;
+}
+
+extern "C" adac_status adac_scan_count_eq(adac_layout *l, const uint64_t *d_words, uint64_t key, uint64_t *d_counts) {
+	if (!l || (l->nseg && !d_counts) || (l->total_values && !d_words)) return ADAC_ERR_INVALID_ARGUMENT;
+	if (!aligned16(d_words)) return ADAC_ERR_INVALID_ARGUMENT;
+	ADAC_HIP(hipSetDevice(l->ctx->device));
+	if (l->nseg) ADAC_HIP(hipMemsetAsync(d_counts, 0, l->nseg * sizeof(uint64_t), l->ctx->stream));
+	ADAC_HIP(adac::launch_scan_count_eq(l->ctx->stream, l->type_size, l->d_descs, l->d_tiles, l->ntiles, d_words, key,
+	                                    d_counts));
+	return ADAC_OK;
+}

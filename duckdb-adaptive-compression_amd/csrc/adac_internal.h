@@ -1,0 +1,56 @@
+// adac_internal.h — launch wrappers shared between the C ABI (adac_capi.cpp) and the gfx950 kernels
+// (adac_kernels.hip).  Not installed; the public surface is include/adacodec.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "adacodec.h"
+
+namespace adac {
+
+constexpr int kWorkgroup = 256;       // 4 wavefronts of 64 lanes
+constexpr int kTileBytes = 16384;     // decoded bytes per tile: tile = 16 KiB / sizeof(T) values
+constexpr uint32_t kNoTile = 0xffffffffu;
+
+// One tile of one segment: `first` is a multiple of the type's tile size.
+struct TileRef {
+	uint32_t seg;
+	uint32_t first;
+};
+
+// Single-segment range decode (scan_vector / scan_partial): tiles are implicit.
+struct RangeArgs {
+	uint32_t seg;
+	uint32_t start;
+	uint32_t count;
+	uint64_t out_off;
+};
+
+inline uint32_t tile_values(uint32_t type_size) {
+	return kTileBytes / type_size;
+}
+
+// type_size in {1,2,4,8}; every launcher returns the hipError_t of the launch.
+hipError_t launch_analyze(hipStream_t s, uint32_t type_size, bool sign_extend, uint64_t null_bits, int rule,
+                          const adac_segment_desc *d_descs, const TileRef *d_tiles, uint64_t ntiles,
+                          const void *d_vals, const uint64_t *d_validity, uint64_t *d_minmax);
+hipError_t launch_minmax_init(hipStream_t s, uint64_t *d_minmax, uint64_t nseg);
+hipError_t launch_plan(hipStream_t s, uint32_t type_size, int rule, int pad_to_byte, adac_segment_desc *d_descs,
+                       const uint64_t *d_minmax, uint64_t nseg);
+hipError_t launch_pack(hipStream_t s, uint32_t type_size, uint64_t null_bits, const adac_segment_desc *d_descs,
+                       const TileRef *d_tiles, uint64_t ntiles, const void *d_vals, const uint64_t *d_validity,
+                       uint64_t *d_words);
+hipError_t launch_unpack(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs, const TileRef *d_tiles,
+                         uint64_t ntiles, const uint64_t *d_words, void *d_out);
+hipError_t launch_unpack_range(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs, RangeArgs range,
+                               const uint64_t *d_words, void *d_out);
+hipError_t launch_fetch(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs, const uint64_t *d_words,
+                        const uint32_t *d_segs, const uint32_t *d_rows, uint64_t n, void *d_out);
+hipError_t launch_scan_sum(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs, const TileRef *d_tiles,
+                           uint64_t ntiles, const uint64_t *d_words, uint64_t *d_sums);
+hipError_t launch_scan_count_eq(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs,
+                                const TileRef *d_tiles, uint64_t ntiles, const uint64_t *d_words, uint64_t key,
+                                uint64_t *d_counts);
+
+} // namespace adac

@@ -1,0 +1,603 @@
+// adac_kernels.hip — gfx950 (MI355X, CDNA4) kernels of the succinct column-segment codec.
+//
+// Pure integer, HBM-bound work: no MFMA.  Common shape of every streaming kernel:
+//   * one 256-thread workgroup (4 wave64) per TILE = 16 KiB of decoded values of ONE segment, tiles
+//     enumerated over all segments of a batch by a device tile table, so a launch has >> 256 workgroups
+//     and ragged / tiny segments cost nothing special;
+//   * global traffic only as 16-byte-per-lane, 16-byte-aligned accesses (1 KiB per wave instruction):
+//     packed words are staged through LDS with dwordx4 loads, decoded values leave as dwordx4 stores;
+//   * no inter-tile reuse, hence no XCD-aware block remap: every byte is touched once.
+//
+// Reference loops these kernels replace (paths relative to the reference checkout):
+//   k_unpack        SuccinctScanPartial                 src/storage/compression/succinct.cpp:123-144
+//                   ColumnSegment::UncompressSuccinct   src/storage/table/column_segment.cpp:458-506
+//   k_analyze       SuccinctAppendLoop min/max          src/storage/compression/succinct.cpp:271-306
+//                   BitCompressFromUncompressed pass 1  src/storage/table/column_segment.cpp:390-400
+//   k_plan          width decision                      src/storage/table/column_segment.cpp:351-363,404-420
+//   k_pack          BitCompressFromSuccinct / ...FromUncompressed pack loops   column_segment.cpp:365-376,426-443
+//   k_fetch         SuccinctFetchRow (intended)         src/storage/compression/succinct.cpp:244-260
+//   bit layout      sdsl::bits::read_int / write_int    third_party/sdsl/include/sdsl/bits.hpp:456-529
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "adac_internal.h"
+
+namespace adac {
+
+namespace {
+
+template <int BYTES> struct uint_of;
+template <> struct uint_of<1> { using type = uint8_t; };
+template <> struct uint_of<2> { using type = uint16_t; };
+template <> struct uint_of<4> { using type = uint32_t; };
+template <> struct uint_of<8> { using type = uint64_t; };
+
+__device__ __forceinline__ uint32_t mask32(uint32_t bits) { // bits in 0..32
+	return bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
+}
+__device__ __forceinline__ uint64_t mask64(uint32_t bits) { // bits in 0..64
+	return bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);
+}
+
+// sdsl::bits::hi (bits.hpp:392-397)
+__device__ __forceinline__ uint32_t hi_bit(uint64_t x) { return x == 0 ? 0u : 63u - (uint32_t)__clzll((long long)x); }
+
+__device__ __forceinline__ uint64_t wave_min(uint64_t v) {
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) {
+		uint64_t o = __shfl_xor(v, off, 64);
+		v = o < v ? o : v;
+	}
+	return v;
+}
+__device__ __forceinline__ uint64_t wave_max(uint64_t v) {
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) {
+		uint64_t o = __shfl_xor(v, off, 64);
+		v = o > v ? o : v;
+	}
+	return v;
+}
+__device__ __forceinline__ uint64_t wave_sum(uint64_t v) {
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) {
+		v += __shfl_xor(v, off, 64);
+	}
+	return v;
+}
+
+// A tile resolved to its segment.
+struct TileCtx {
+	adac_segment_desc d;
+	uint32_t seg;
+	uint32_t first;  // first row of the tile inside the segment
+	uint32_t n;      // rows in the tile
+	uint64_t elem0;  // element index of row `first` in the value buffer
+};
+
+template <int TILE>
+__device__ __forceinline__ TileCtx resolve_tile(const adac_segment_desc *__restrict__ descs,
+                                                const TileRef *__restrict__ tiles) {
+	TileCtx t;
+	const TileRef r = tiles[blockIdx.x];
+	t.seg = r.seg;
+	t.first = r.first;
+	t.d = descs[r.seg];
+	const uint32_t left = t.d.count - r.first;
+	t.n = left < (uint32_t)TILE ? left : (uint32_t)TILE;
+	t.elem0 = t.d.val_off + r.first;
+	return t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage the packed bits of rows [first, first+n) of a segment into LDS with 16-byte loads.
+// Returns the bit offset (0..127) of row `first` inside the staged image.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t stage_packed(const uint64_t *__restrict__ seg_words, uint32_t first, uint32_t n,
+                                                 uint32_t w, uint4 *lds) {
+	const uint64_t bitpos = (uint64_t)first * w;
+	const uint64_t chunk0 = bitpos >> 7; // 16-byte chunk holding the first bit
+	const uint32_t bit0 = (uint32_t)(bitpos & 127);
+	const uint32_t nchunks = (bit0 + n * w + 127u) >> 7;
+	const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(seg_words) + chunk0;
+	for (uint32_t c = threadIdx.x; c < nchunks; c += kWorkgroup) {
+		lds[c] = src[c];
+	}
+	return bit0;
+}
+
+// Read the w-bit field at `bit` of the staged image (sdsl::bits::read_int, bits.hpp:501-511) as lo/hi dwords.
+template <bool WIDE>
+__device__ __forceinline__ void read_field(const uint32_t *lds32, uint32_t bit, uint32_t mlo, uint32_t mhi,
+                                           uint32_t &lo, uint32_t &hi) {
+	const uint32_t dw = bit >> 5;
+	const uint32_t sh = bit & 31u;
+	const uint32_t a0 = lds32[dw];
+	const uint32_t a1 = lds32[dw + 1];
+	lo = __builtin_amdgcn_alignbit(a1, a0, sh);
+	if (WIDE) {
+		const uint32_t a2 = lds32[dw + 2];
+		hi = __builtin_amdgcn_alignbit(a2, a1, sh) & mhi;
+	} else {
+		lo &= mlo;
+		hi = 0;
+	}
+}
+
+// Walk the rows of a staged tile in chunks of K = 16/sizeof(U) consecutive rows, chunk boundaries aligned to
+// 16 bytes of the OUTPUT element index (elem0 + row), so a sink can use one dwordx4 store per full chunk.
+// sink(base, vals, full): `base` = tile-local row of vals[0] (may be < 0 or run past n on partial chunks).
+template <typename U, bool WIDE, typename Sink>
+__device__ __forceinline__ void decode_rows(const uint32_t *lds32, uint32_t bit0, uint32_t w, uint64_t add, uint32_t n,
+                                            uint32_t align, Sink &&sink) {
+	constexpr int K = 16 / (int)sizeof(U);
+	const uint32_t mlo = WIDE ? 0xffffffffu : mask32(w);
+	const uint32_t mhi = WIDE ? mask32(w - 32u) : 0u;
+	const uint32_t add_lo = (uint32_t)add;
+	for (uint32_t c = threadIdx.x; c * K < n + align; c += kWorkgroup) {
+		const int32_t base = (int32_t)(c * K) - (int32_t)align;
+		U vals[K];
+#pragma unroll
+		for (int j = 0; j < K; j++) {
+			const uint32_t row = (uint32_t)(base + j);
+			const uint32_t r = row < n ? row : 0u;
+			uint32_t lo, hi;
+			read_field<WIDE>(lds32, bit0 + r * w, mlo, mhi, lo, hi);
+			if (sizeof(U) == 8) {
+				vals[j] = (U)((((uint64_t)hi << 32) | lo) + add);
+			} else {
+				vals[j] = (U)(lo + add_lo);
+			}
+		}
+		const bool full = base >= 0 && (uint32_t)(base + K) <= n;
+		sink(base, vals, full);
+	}
+}
+
+__device__ __forceinline__ uint64_t effective_add(const adac_segment_desc &d) {
+	// product rule: the frame of reference is added back only where it was subtracted
+	return ((d.flags & ADAC_SEG_PACKED) && d.min != ADAC_NO_MIN) ? d.min : 0ull;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_unpack — decode.  LDS: the packed image of one tile (<= 16 KiB + 32 B).
+// ---------------------------------------------------------------------------------------------
+template <typename U>
+struct StoreSink {
+	U *dst; // element `elem0` of the output
+	uint32_t n;
+	__device__ __forceinline__ void operator()(int32_t base, const U *vals, bool full) const {
+		constexpr int K = 16 / (int)sizeof(U);
+		if (full) {
+			uint4 q;
+			__builtin_memcpy(&q, vals, 16);
+			*reinterpret_cast<uint4 *>(dst + base) = q;
+		} else {
+#pragma unroll
+			for (int j = 0; j < K; j++) {
+				if ((uint32_t)(base + j) < n) dst[base + j] = vals[j];
+			}
+		}
+	}
+};
+
+template <typename U, bool RANGE>
+__global__ __launch_bounds__(kWorkgroup) void k_unpack(const adac_segment_desc *__restrict__ descs,
+                                                       const TileRef *__restrict__ tiles, RangeArgs range,
+                                                       const uint64_t *__restrict__ words, U *__restrict__ out) {
+	constexpr int TILE = kTileBytes / (int)sizeof(U);
+	__shared__ uint4 lds[kTileBytes / 16 + 2];
+	adac_segment_desc d;
+	uint32_t first, n;
+	uint64_t elem0;
+	if (RANGE) {
+		d = descs[range.seg];
+		const uint32_t done = blockIdx.x * (uint32_t)TILE;
+		first = range.start + done;
+		const uint32_t left = range.count - done;
+		n = left < (uint32_t)TILE ? left : (uint32_t)TILE;
+		elem0 = range.out_off + done;
+	} else {
+		const TileCtx t = resolve_tile<TILE>(descs, tiles);
+		d = t.d;
+		first = t.first;
+		n = t.n;
+		elem0 = t.elem0;
+	}
+	const uint32_t w = d.width;
+	const uint32_t bit0 = stage_packed(words + d.word_off, first, n, w, lds);
+	__syncthreads();
+	const uint64_t add = effective_add(d);
+	constexpr uint32_t K = 16 / sizeof(U);
+	const uint32_t align = (uint32_t)(elem0 & (K - 1));
+	StoreSink<U> sink {out + elem0, n};
+	const uint32_t *lds32 = reinterpret_cast<const uint32_t *>(lds);
+	if (sizeof(U) == 8 && w > 32) {
+		decode_rows<U, true>(lds32, bit0, w, add, n, align, sink);
+	} else {
+		decode_rows<U, false>(lds32, bit0, w, add, n, align, sink);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_scan_sum / k_scan_count_eq — fused scan + aggregate, nothing materialised.
+// ---------------------------------------------------------------------------------------------
+template <typename U, int OP> // OP 0: sum, 1: count == key
+__global__ __launch_bounds__(kWorkgroup) void k_scan_agg(const adac_segment_desc *__restrict__ descs,
+                                                         const TileRef *__restrict__ tiles,
+                                                         const uint64_t *__restrict__ words, uint64_t key,
+                                                         uint64_t *__restrict__ result) {
+	constexpr int TILE = kTileBytes / (int)sizeof(U);
+	__shared__ uint4 lds[kTileBytes / 16 + 2];
+	__shared__ uint64_t partial[kWorkgroup / 64];
+	const TileCtx t = resolve_tile<TILE>(descs, tiles);
+	const uint32_t w = t.d.width;
+	const uint32_t bit0 = stage_packed(words + t.d.word_off, t.first, t.n, w, lds);
+	__syncthreads();
+	const uint64_t add = effective_add(t.d);
+	uint64_t acc = 0;
+	const uint32_t n = t.n;
+	const U k = (U)key;
+	auto sink = [&](int32_t base, const U *vals, bool full) {
+		constexpr int K = 16 / (int)sizeof(U);
+#pragma unroll
+		for (int j = 0; j < K; j++) {
+			if (full || (uint32_t)(base + j) < n) {
+				acc += OP == 0 ? (uint64_t)vals[j] : (uint64_t)(vals[j] == k);
+			}
+		}
+	};
+	const uint32_t *lds32 = reinterpret_cast<const uint32_t *>(lds);
+	if (sizeof(U) == 8 && w > 32) {
+		decode_rows<U, true>(lds32, bit0, w, add, n, 0u, sink);
+	} else {
+		decode_rows<U, false>(lds32, bit0, w, add, n, 0u, sink);
+	}
+	acc = wave_sum(acc);
+	if ((threadIdx.x & 63) == 0) partial[threadIdx.x >> 6] = acc;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint64_t s = 0;
+#pragma unroll
+		for (int i = 0; i < kWorkgroup / 64; i++) s += partial[i];
+		atomicAdd(reinterpret_cast<unsigned long long *>(result + t.seg), (unsigned long long)s);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// Raw value access shared by k_analyze and k_pack: chunks of K rows aligned to 16 bytes of the element index.
+// ---------------------------------------------------------------------------------------------
+template <typename U>
+__device__ __forceinline__ void load_chunk(const U *__restrict__ src /* element elem0 */, int32_t base, uint32_t n,
+                                           U *vals) {
+	constexpr int K = 16 / (int)sizeof(U);
+	if (base >= 0 && (uint32_t)(base + K) <= n) {
+		const uint4 q = *reinterpret_cast<const uint4 *>(src + base);
+		__builtin_memcpy(vals, &q, 16);
+	} else {
+#pragma unroll
+		for (int j = 0; j < K; j++) {
+			vals[j] = (uint32_t)(base + j) < n ? src[base + j] : (U)0;
+		}
+	}
+}
+
+__device__ __forceinline__ bool row_valid(const uint64_t *__restrict__ validity, uint64_t elem) {
+	return validity == nullptr || ((validity[elem >> 6] >> (elem & 63)) & 1ull);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_analyze — per-segment min/max.  Per-lane running min/max, wave64 xor-shuffle reduce, 4 partials through
+// LDS, one atomic min + one atomic max per tile (order-independent, so deterministic).
+// ---------------------------------------------------------------------------------------------
+template <typename U>
+__global__ __launch_bounds__(kWorkgroup) void k_analyze(const adac_segment_desc *__restrict__ descs,
+                                                        const TileRef *__restrict__ tiles,
+                                                        const U *__restrict__ vals,
+                                                        const uint64_t *__restrict__ validity, int sign_extend,
+                                                        uint64_t null_bits, int rule,
+                                                        uint64_t *__restrict__ minmax) {
+	constexpr int TILE = kTileBytes / (int)sizeof(U);
+	constexpr int K = 16 / (int)sizeof(U);
+	using S = typename std::make_signed<U>::type;
+	__shared__ uint64_t pmin[kWorkgroup / 64], pmax[kWorkgroup / 64];
+	const TileCtx t = resolve_tile<TILE>(descs, tiles);
+	const U *src = vals + t.elem0;
+	const uint32_t align = (uint32_t)(t.elem0 & (K - 1));
+	uint64_t mn = ~0ull, mx = 0;
+	for (uint32_t c = threadIdx.x; c * K < t.n + align; c += kWorkgroup) {
+		const int32_t base = (int32_t)(c * K) - (int32_t)align;
+		U v[K];
+		load_chunk<U>(src, base, t.n, v);
+#pragma unroll
+		for (int j = 0; j < K; j++) {
+			if ((uint32_t)(base + j) >= t.n) continue;
+			const bool valid = row_valid(validity, t.elem0 + (int64_t)(base + j));
+			uint64_t x;
+			if (rule == ADAC_RULE_APPEND) {
+				// succinct.cpp:286-287: uint64_t(sdata[i]); NULL rows do not take part
+				if (!valid) continue;
+				x = sign_extend ? (uint64_t)(int64_t)(S)v[j] : (uint64_t)v[j];
+			} else {
+				// column_segment.cpp:392-399: every slot, zero-extended; NULL slots hold NullValue<T>
+				x = valid ? (uint64_t)v[j] : null_bits;
+			}
+			mn = x < mn ? x : mn;
+			mx = x > mx ? x : mx;
+		}
+	}
+	mn = wave_min(mn);
+	mx = wave_max(mx);
+	if ((threadIdx.x & 63) == 0) {
+		pmin[threadIdx.x >> 6] = mn;
+		pmax[threadIdx.x >> 6] = mx;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+#pragma unroll
+		for (int i = 1; i < kWorkgroup / 64; i++) {
+			mn = pmin[i] < mn ? pmin[i] : mn;
+			mx = pmax[i] > mx ? pmax[i] : mx;
+		}
+		atomicMin(reinterpret_cast<unsigned long long *>(minmax + 2 * (uint64_t)t.seg), (unsigned long long)mn);
+		atomicMax(reinterpret_cast<unsigned long long *>(minmax + 2 * (uint64_t)t.seg + 1), (unsigned long long)mx);
+	}
+}
+
+__global__ void k_minmax_init(uint64_t *__restrict__ minmax, uint64_t nseg) {
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < nseg) {
+		minmax[2 * i] = ~0ull; // ColumnSegment ctor: min_factor(UINT64_MAX), max_factor(0)  column_segment.cpp:94
+		minmax[2 * i + 1] = 0;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_plan — widths, flags and arena offsets for every segment, on the device (one workgroup, chunked scan).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t width_for(uint64_t mn, uint64_t mx, int rule, int pad) {
+	uint32_t w;
+	if (rule == ADAC_RULE_APPEND) {
+		w = hi_bit(mx - mn) + 1; // column_segment.cpp:351-354 (wrapping u64 arithmetic)
+	} else {
+		if (mx != 0 && mn != ~0ull && mx > mn) mx -= mn; // column_segment.cpp:404-407
+		w = hi_bit(mx) + 1;
+	}
+	if (pad) w = (w + 7u) & ~7u; // column_segment.cpp:356-359
+	return w;
+}
+
+constexpr int kPlanThreads = 1024;
+
+__global__ __launch_bounds__(kPlanThreads) void k_plan(adac_segment_desc *__restrict__ descs,
+                                                       const uint64_t *__restrict__ minmax, uint64_t nseg,
+                                                       uint32_t type_bits, int rule, int pad) {
+	__shared__ uint64_t scan[kPlanThreads];
+	__shared__ uint64_t carry;
+	if (threadIdx.x == 0) carry = 0;
+	__syncthreads();
+	for (uint64_t base = 0; base < nseg; base += kPlanThreads) {
+		const uint64_t s = base + threadIdx.x;
+		uint64_t fp = 0;
+		uint32_t w = type_bits;
+		uint8_t flags = 0;
+		uint64_t mn = ~0ull;
+		if (s < nseg) {
+			mn = minmax[2 * s];
+			const uint64_t mx = minmax[2 * s + 1];
+			const uint32_t cand = width_for(mn, mx, rule, pad);
+			if (type_bits > cand) { // `if (old_width > min_width)` column_segment.cpp:363,420
+				w = cand;
+				flags = ADAC_SEG_PACKED;
+			}
+			const uint64_t bits = (uint64_t)descs[s].count * w;
+			fp = (((bits + 64) >> 6) + 15) & ~15ull; // SDSL allocation, rounded to 128 B
+		}
+		scan[threadIdx.x] = fp;
+		__syncthreads();
+		for (int off = 1; off < kPlanThreads; off <<= 1) { // Hillis-Steele inclusive scan
+			uint64_t v = threadIdx.x >= (uint32_t)off ? scan[threadIdx.x - off] : 0;
+			__syncthreads();
+			scan[threadIdx.x] += v;
+			__syncthreads();
+		}
+		if (s < nseg) {
+			descs[s].word_off = carry + scan[threadIdx.x] - fp;
+			descs[s].min = mn;
+			descs[s].width = (uint8_t)w;
+			descs[s].flags = flags;
+			descs[s].reserved = 0;
+		}
+		__syncthreads();
+		if (threadIdx.x == kPlanThreads - 1) carry += scan[threadIdx.x];
+		__syncthreads();
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_pack — bit-pack one tile.  Phase 1: (x - min) mod 2^w of every row into LDS (as U: w <= 8*sizeof(U)).
+// Phase 2: each lane OWNS whole output uint64 words and gathers the rows that overlap its word — no atomics,
+// no read-modify-write, coalesced 8-byte stores; tail bits of the last word come out zero by construction.
+// Tiles start at multiples of TILE (a multiple of 64 rows), so a tile's bits start on a word boundary.
+// ---------------------------------------------------------------------------------------------
+template <typename U>
+__global__ __launch_bounds__(kWorkgroup) void k_pack(const adac_segment_desc *__restrict__ descs,
+                                                     const TileRef *__restrict__ tiles, const U *__restrict__ vals,
+                                                     const uint64_t *__restrict__ validity, uint64_t null_bits,
+                                                     uint64_t *__restrict__ words) {
+	constexpr int TILE = kTileBytes / (int)sizeof(U);
+	constexpr int K = 16 / (int)sizeof(U);
+	__shared__ U delta[TILE];
+	const TileCtx t = resolve_tile<TILE>(descs, tiles);
+	const uint32_t w = t.d.width;
+	const bool packed = (t.d.flags & ADAC_SEG_PACKED) != 0;
+	const uint64_t sub = (packed && t.d.min != ADAC_NO_MIN) ? t.d.min : 0ull; // column_segment.cpp:371-373
+	const U wmask = (U)mask64(w);
+	const U *src = vals + t.elem0;
+	const uint32_t align = (uint32_t)(t.elem0 & (K - 1));
+	for (uint32_t c = threadIdx.x; c * K < t.n + align; c += kWorkgroup) {
+		const int32_t base = (int32_t)(c * K) - (int32_t)align;
+		U v[K];
+		load_chunk<U>(src, base, t.n, v);
+#pragma unroll
+		for (int j = 0; j < K; j++) {
+			const uint32_t row = (uint32_t)(base + j);
+			if (row >= t.n) continue;
+			const bool valid = row_valid(validity, t.elem0 + row);
+			const U x = valid ? v[j] : (U)null_bits;
+			delta[row] = (U)(x - (U)sub) & wmask; // low w bits of (x - min): w <= 8*sizeof(U)
+		}
+	}
+	__syncthreads();
+	const uint64_t word0 = ((uint64_t)t.first * w) >> 6;
+	const uint32_t nwords = (t.n * w + 63u) >> 6;
+	uint64_t *__restrict__ dst = words + t.d.word_off + word0;
+	for (uint32_t q = threadIdx.x; q < nwords; q += kWorkgroup) {
+		const uint32_t bitlo = q << 6;
+		uint32_t i = bitlo / w;
+		uint32_t last = (bitlo + 63u) / w;
+		last = last < t.n ? last : t.n - 1;
+		uint64_t acc = 0;
+		for (; i <= last; i++) {
+			const uint64_t v = (uint64_t)delta[i];
+			const int32_t pos = (int32_t)(i * w) - (int32_t)bitlo;
+			acc |= pos >= 0 ? (v << pos) : (v >> (-pos));
+		}
+		dst[q] = acc;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_fetch — point look-ups straight from HBM (two 8-byte loads per row).
+// ---------------------------------------------------------------------------------------------
+template <typename U>
+__global__ __launch_bounds__(kWorkgroup) void k_fetch(const adac_segment_desc *__restrict__ descs,
+                                                      const uint64_t *__restrict__ words,
+                                                      const uint32_t *__restrict__ segs,
+                                                      const uint32_t *__restrict__ rows, uint64_t n,
+                                                      U *__restrict__ out) {
+	const uint64_t k = (uint64_t)blockIdx.x * kWorkgroup + threadIdx.x;
+	if (k >= n) return;
+	const adac_segment_desc d = descs[segs[k]];
+	const uint32_t w = d.width;
+	const uint64_t bit = (uint64_t)rows[k] * w;
+	const uint64_t *p = words + d.word_off + (bit >> 6);
+	const uint32_t off = (uint32_t)(bit & 63);
+	uint64_t v = p[0] >> off;
+	if (off + w > 64) v |= p[1] << (64 - off);
+	v &= mask64(w);
+	out[k] = (U)(v + effective_add(d));
+}
+
+template <typename F>
+hipError_t dispatch_size(uint32_t type_size, F &&f) {
+	switch (type_size) {
+	case 1: return f(uint8_t {});
+	case 2: return f(uint16_t {});
+	case 4: return f(uint32_t {});
+	case 8: return f(uint64_t {});
+	default: return hipErrorInvalidValue;
+	}
+}
+
+} // namespace
+
+hipError_t launch_minmax_init(hipStream_t s, uint64_t *d_minmax, uint64_t nseg) {
+	if (nseg == 0) return hipSuccess;
+	hipLaunchKernelGGL(k_minmax_init, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, s, d_minmax, nseg);
+	return hipGetLastError();
+}
+
+hipError_t launch_analyze(hipStream_t s, uint32_t type_size, bool sign_extend, uint64_t null_bits, int rule,
+                          const adac_segment_desc *d_descs, const TileRef *d_tiles, uint64_t ntiles,
+                          const void *d_vals, const uint64_t *d_validity, uint64_t *d_minmax) {
+	if (ntiles == 0) return hipSuccess;
+	return dispatch_size(type_size, [&](auto tag) {
+		using U = decltype(tag);
+		hipLaunchKernelGGL(k_analyze<U>, dim3((unsigned)ntiles), dim3(kWorkgroup), 0, s, d_descs, d_tiles,
+		                   static_cast<const U *>(d_vals), d_validity, sign_extend ? 1 : 0, null_bits, rule, d_minmax);
+		return hipGetLastError();
+	});
+}
+
+hipError_t launch_plan(hipStream_t s, uint32_t type_size, int rule, int pad_to_byte, adac_segment_desc *d_descs,
+                       const uint64_t *d_minmax, uint64_t nseg) {
+	if (nseg == 0) return hipSuccess;
+	hipLaunchKernelGGL(k_plan, dim3(1), dim3(kPlanThreads), 0, s, d_descs, d_minmax, nseg, type_size * 8, rule,
+	                   pad_to_byte);
+	return hipGetLastError();
+}
+
+hipError_t launch_pack(hipStream_t s, uint32_t type_size, uint64_t null_bits, const adac_segment_desc *d_descs,
+                       const TileRef *d_tiles, uint64_t ntiles, const void *d_vals, const uint64_t *d_validity,
+                       uint64_t *d_words) {
+	if (ntiles == 0) return hipSuccess;
+	return dispatch_size(type_size, [&](auto tag) {
+		using U = decltype(tag);
+		hipLaunchKernelGGL(k_pack<U>, dim3((unsigned)ntiles), dim3(kWorkgroup), 0, s, d_descs, d_tiles,
+		                   static_cast<const U *>(d_vals), d_validity, null_bits, d_words);
+		return hipGetLastError();
+	});
+}
+
+hipError_t launch_unpack(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs, const TileRef *d_tiles,
+                         uint64_t ntiles, const uint64_t *d_words, void *d_out) {
+	if (ntiles == 0) return hipSuccess;
+	return dispatch_size(type_size, [&](auto tag) {
+		using U = decltype(tag);
+		hipLaunchKernelGGL((k_unpack<U, false>), dim3((unsigned)ntiles), dim3(kWorkgroup), 0, s, d_descs, d_tiles,
+		                   RangeArgs {}, d_words, static_cast<U *>(d_out));
+		return hipGetLastError();
+	});
+}
+
+hipError_t launch_unpack_range(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs, RangeArgs range,
+                               const uint64_t *d_words, void *d_out) {
+	if (range.count == 0) return hipSuccess;
+	return dispatch_size(type_size, [&](auto tag) {
+		using U = decltype(tag);
+		const uint32_t tile = kTileBytes / sizeof(U);
+		const uint32_t nt = (range.count + tile - 1) / tile;
+		hipLaunchKernelGGL((k_unpack<U, true>), dim3(nt), dim3(kWorkgroup), 0, s, d_descs,
+		                   static_cast<const TileRef *>(nullptr), range, d_words, static_cast<U *>(d_out));
+		return hipGetLastError();
+	});
+}
+
+hipError_t launch_fetch(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs, const uint64_t *d_words,
+                        const uint32_t *d_segs, const uint32_t *d_rows, uint64_t n, void *d_out) {
+	if (n == 0) return hipSuccess;
+	return dispatch_size(type_size, [&](auto tag) {
+		using U = decltype(tag);
+		hipLaunchKernelGGL(k_fetch<U>, dim3((unsigned)((n + kWorkgroup - 1) / kWorkgroup)), dim3(kWorkgroup), 0, s,
+		                   d_descs, d_words, d_segs, d_rows, n, static_cast<U *>(d_out));
+		return hipGetLastError();
+	});
+}
+
+hipError_t launch_scan_sum(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs, const TileRef *d_tiles,
+                           uint64_t ntiles, const uint64_t *d_words, uint64_t *d_sums) {
+	if (ntiles == 0) return hipSuccess;
+	return dispatch_size(type_size, [&](auto tag) {
+		using U = decltype(tag);
+		hipLaunchKernelGGL((k_scan_agg<U, 0>), dim3((unsigned)ntiles), dim3(kWorkgroup), 0, s, d_descs, d_tiles,
+		                   d_words, (uint64_t)0, d_sums);
+		return hipGetLastError();
+	});
+}
+
+hipError_t launch_scan_count_eq(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs,
+                                const TileRef *d_tiles, uint64_t ntiles, const uint64_t *d_words, uint64_t key,
+                                uint64_t *d_counts) {
+	if (ntiles == 0) return hipSuccess;
+	return dispatch_size(type_size, [&](auto tag) {
+		using U = decltype(tag);
+		hipLaunchKernelGGL((k_scan_agg<U, 1>), dim3((unsigned)ntiles), dim3(kWorkgroup), 0, s, d_descs, d_tiles,
+		                   d_words, key, d_counts);
+		return hipGetLastError();
+	});
+}
+
+} // namespace adac

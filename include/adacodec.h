@@ -1,0 +1,208 @@
+/*
+ * adacodec.h — C ABI of libadacodec: the MI355X (gfx950) succinct column-segment codec.
+ *
+ * This is the drop-in boundary for ONE path of leonwind/duckdb-adaptive-compression: the per-segment
+ * bit-packed integer codec behind DuckDB's COMPRESSION_SUCCINCT function table.  Every entry point names
+ * the reference interface it replaces (paths relative to the reference checkout).  Plain C types only:
+ * pointers named d_* are DEVICE pointers (HBM), everything else is host memory.  No entry point falls back
+ * to a CPU implementation: without a usable gfx950 device the device functions return ADAC_ERR_NO_DEVICE.
+ *
+ * Packed format (identical to sdsl::int_vector<0>, third_party/sdsl/include/sdsl/int_vector.hpp:289-327,
+ * bits.hpp:456-529): value i of a segment occupies bits [i*w, (i+1)*w) of a little-endian uint64 stream,
+ * LSB first, may straddle one word boundary; stored value = (x - min) mod 2^w; bits past count*w in the last
+ * word are zero.  The integration glue (C++ adapter a DuckDB maintainer would add) is in INTEGRATION.md.
+ */
+#ifndef ADACODEC_H
+#define ADACODEC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADAC_ABI_VERSION 1
+
+typedef enum adac_status {
+	ADAC_OK = 0,
+	ADAC_ERR_INVALID_ARGUMENT = 1,
+	ADAC_ERR_UNSUPPORTED_TYPE = 2, /* InternalException("Unsupported type ...") succinct.cpp:364 */
+	ADAC_ERR_DEVICE = 3,           /* a HIP call failed; adac_last_error() has the text */
+	ADAC_ERR_OUT_OF_MEMORY = 4,
+	ADAC_ERR_NO_DEVICE = 5
+} adac_status;
+
+/* duckdb::PhysicalType codes of the eight supported types (src/include/duckdb/common/types.hpp:117-138;
+ * supported set: SuccinctFun::TypeIsSupported, src/storage/compression/succinct.cpp:368-382). */
+typedef enum adac_type {
+	ADAC_UINT8 = 2,
+	ADAC_INT8 = 3,
+	ADAC_UINT16 = 4,
+	ADAC_INT16 = 5,
+	ADAC_UINT32 = 6,
+	ADAC_INT32 = 7,
+	ADAC_UINT64 = 8,
+	ADAC_INT64 = 9
+} adac_type;
+
+/* Which of the reference's two encode paths produced / should produce a segment's min, max and width. */
+typedef enum adac_rule {
+	/* SuccinctAppendLoop + BitCompressFromSuccinct (succinct.cpp:271-306, column_segment.cpp:348-383):
+	 * min/max over uint64_t(T x) (sign-extended for signed T), NULL rows excluded; w = hi(max-min)+1. */
+	ADAC_RULE_APPEND = 0,
+	/* BitCompressFromUncompressed (column_segment.cpp:385-456): min/max over the raw block zero-extended,
+	 * NULL slots (NullValue<T>) included; max reduced by min only when max > min, so a constant non-zero
+	 * segment keeps w = hi(value)+1. */
+	ADAC_RULE_RECOMPACT = 1
+} adac_rule;
+
+#define ADAC_NO_MIN UINT64_MAX /* ColumnSegment::min_factor initial value: no frame of reference */
+#define ADAC_SEG_PACKED 0x1u   /* width < 8*sizeof(T) and (x - min) stored; clear = raw slots at 8*sizeof(T) */
+
+/* One column segment as the device sees it (32 bytes).  Mirrors the succinct members of
+ * duckdb::ColumnSegment (src/include/duckdb/storage/table/column_segment.hpp:60-64,190-214):
+ * succinct_vec.{data,width}, count, min_factor, compacted. */
+typedef struct adac_segment_desc {
+	uint64_t word_off; /* first uint64 word of the segment in the packed arena; multiple of 16 (128 B) */
+	uint64_t val_off;  /* first element of the segment in the raw / decoded value buffer */
+	uint64_t min;      /* min_factor, ADAC_NO_MIN if none */
+	uint32_t count;    /* values in the segment */
+	uint8_t width;     /* bits per stored value, 1..64 */
+	uint8_t flags;     /* ADAC_SEG_* */
+	uint16_t reserved;
+} adac_segment_desc;
+
+typedef struct adac_ctx adac_ctx;       /* one device + one HIP stream */
+typedef struct adac_layout adac_layout; /* a batch of segments: counts, placement, device tables */
+
+/* ---------------------------------------------------------------------------------------------
+ * Host-only helpers (never touch the device).
+ * ------------------------------------------------------------------------------------------- */
+
+int adac_abi_version(void);
+const char *adac_status_string(adac_status s);
+const char *adac_last_error(void); /* thread-local text of the last ADAC_ERR_DEVICE */
+
+/* SuccinctFun::TypeIsSupported (succinct.cpp:368-382) */
+int adac_type_is_supported(int physical_type);
+/* GetTypeIdSize for the supported types; 0 if unsupported */
+uint32_t adac_type_size(int physical_type);
+/* sdsl::bits::hi (bits.hpp:392-397): index of the highest set bit, hi(0) == 0 */
+uint32_t adac_hi(uint64_t x);
+/* Minimal width for a segment: column_segment.cpp:351-359 (rule APPEND) / :404-417 (rule RECOMPACT);
+ * pad_to_byte = DBConfig::succinct_padded_to_next_byte_enabled (config.hpp:193). */
+uint8_t adac_width(uint64_t min, uint64_t max, int rule, int pad_to_byte);
+/* ceil(count*width/64): logical uint64 words of a packed segment (int_vector::capacity()/64) */
+uint64_t adac_packed_words(uint64_t count, uint8_t width);
+/* sdsl::size_in_bytes(succinct_vec) = 9 + 8*ceil(count*width/64) (io.hpp:636-640,
+ * int_vector.hpp:602-609,1565-1578): what ColumnSegment::GetDataSize reports (column_segment.cpp:204-214) */
+uint64_t adac_size_in_bytes(uint64_t count, uint8_t width);
+/* words a segment occupies in the packed arena: the SDSL allocation ((bits+64)>>6 words,
+ * memory_management.hpp:353) rounded up to 128 B */
+uint64_t adac_arena_words(uint64_t count, uint8_t width);
+/* values per device tile for a type (16 KiB of decoded output) */
+uint32_t adac_tile_values(int physical_type);
+
+/* ---------------------------------------------------------------------------------------------
+ * Context and device memory.
+ * ------------------------------------------------------------------------------------------- */
+
+/* Binds to HIP device `device`.  external_stream: a hipStream_t owned by the caller (e.g. the engine's or
+ * torch's current stream) or NULL to create a private non-blocking stream. */
+adac_status adac_ctx_create(int device, void *external_stream, adac_ctx **out);
+void adac_ctx_destroy(adac_ctx *ctx);
+adac_status adac_ctx_sync(adac_ctx *ctx);
+void *adac_ctx_stream(adac_ctx *ctx); /* the hipStream_t every launch of this ctx goes to */
+int adac_ctx_device(adac_ctx *ctx);
+
+adac_status adac_dev_alloc(adac_ctx *ctx, size_t bytes, void **d_ptr);
+adac_status adac_dev_free(adac_ctx *ctx, void *d_ptr);
+adac_status adac_dev_memset(adac_ctx *ctx, void *d_ptr, int byte, size_t bytes);   /* stream-ordered */
+adac_status adac_memcpy_h2d(adac_ctx *ctx, void *d_dst, const void *src, size_t bytes); /* blocking */
+adac_status adac_memcpy_d2h(adac_ctx *ctx, void *dst, const void *d_src, size_t bytes); /* blocking */
+
+/* HIP-event stopwatch on the ctx stream (for measuring kernels where they are launched). */
+adac_status adac_timer_start(adac_ctx *ctx);
+adac_status adac_timer_stop(adac_ctx *ctx, float *elapsed_ms); /* records, synchronises, reads */
+
+/* ---------------------------------------------------------------------------------------------
+ * Layout: a batch of segments of one physical type.
+ * ------------------------------------------------------------------------------------------- */
+
+/* counts[i]: values in segment i (ColumnSegment::count).  val_offs[i]: element offset of segment i in the
+ * value buffer handed to analyze/pack/unpack, or NULL for back-to-back placement.  Builds the device tile
+ * table; descriptors start with width = 8*sizeof(T), min = ADAC_NO_MIN, not packed (the state of a fresh
+ * transient SUCCINCT segment, column_segment.cpp:101-105). */
+adac_status adac_layout_create(adac_ctx *ctx, int physical_type, const uint32_t *counts, const uint64_t *val_offs,
+                               uint64_t nseg, adac_layout **out);
+void adac_layout_destroy(adac_layout *l);
+uint64_t adac_layout_nseg(const adac_layout *l);
+uint64_t adac_layout_ntiles(const adac_layout *l);
+uint64_t adac_layout_total_values(const adac_layout *l);
+/* elements the value buffer must hold: max(val_off + count) */
+uint64_t adac_layout_value_span(const adac_layout *l);
+/* upper bound of the packed arena in uint64 words for ANY widths (every segment unpacked) */
+uint64_t adac_layout_max_arena_words(const adac_layout *l);
+/* Upload host descriptors (decode of segments encoded elsewhere). word_off must be a multiple of 16. */
+adac_status adac_layout_set_descs(adac_layout *l, const adac_segment_desc *descs);
+/* Download the device descriptors (after adac_plan / adac_encode).  Synchronises the stream. */
+adac_status adac_layout_get_descs(adac_layout *l, adac_segment_desc *descs);
+/* Download per-segment {min,max} pairs (2*nseg uint64) left by adac_analyze.  Synchronises. */
+adac_status adac_layout_get_minmax(adac_layout *l, uint64_t *minmax);
+/* The device copy of the descriptor table (nseg entries), for callers that chain their own kernels. */
+const adac_segment_desc *adac_layout_device_descs(const adac_layout *l);
+
+/* ---------------------------------------------------------------------------------------------
+ * Hot path.  All calls enqueue on the ctx stream and return without synchronising.
+ * ------------------------------------------------------------------------------------------- */
+
+/* Per-segment min/max.  Replaces the running min/max of SuccinctAppendLoop (succinct.cpp:271-306; rule
+ * APPEND) and pass 1 of BitCompressFromUncompressed (column_segment.cpp:390-400; rule RECOMPACT).
+ * d_vals: raw values of type T at element offsets val_off.  d_validity: DuckDB validity mask over the same
+ * element index space (bit e of word e/64 set = row valid) or NULL = all valid. */
+adac_status adac_analyze(adac_layout *l, const void *d_vals, const uint64_t *d_validity, int rule);
+
+/* From the min/max left by adac_analyze compute every segment's width, flags, stored min and arena offset
+ * on the device (no host round trip).  Replaces the width decision of column_segment.cpp:351-363 /
+ * :404-420.  A segment whose width would not shrink (8*sizeof(T) <= w) stays unpacked. */
+adac_status adac_plan(adac_layout *l, int rule, int pad_to_byte);
+
+/* Bit-pack every segment: words[word_off + ...] <- (x - min) mod 2^w.  Replaces the pack loops of
+ * BitCompressFromSuccinct (column_segment.cpp:365-376) and BitCompressFromUncompressed (:426-443).
+ * NULL slots are stored as NullValue<T> - min (succinct.cpp:288-291, null_value.hpp:26-28). */
+adac_status adac_pack(adac_layout *l, const void *d_vals, const uint64_t *d_validity, uint64_t *d_words);
+
+/* analyze + plan + pack */
+adac_status adac_encode(adac_layout *l, const void *d_vals, const uint64_t *d_validity, int rule, int pad_to_byte,
+                        uint64_t *d_words);
+
+/* Decode every segment: out[val_off + i] = T(read_int(words, i*w, w) + min).  Replaces SuccinctScanPartial
+ * over a whole column (succinct.cpp:123-144) and ColumnSegment::UncompressSuccinct (column_segment.cpp:458-506).
+ * Unpacked segments are copied without the min add (SURVEY.md §8a parity domain (iii)).
+ * d_out must be 16-byte aligned. */
+adac_status adac_unpack(adac_layout *l, const uint64_t *d_words, void *d_out);
+
+/* Decode `count` values of ONE segment starting at row `start` to d_out[out_off ...]: the scan_vector /
+ * scan_partial slots (compression_function.hpp:84-88; succinct.cpp:123-144,232-240). */
+adac_status adac_unpack_range(adac_layout *l, const uint64_t *d_words, uint64_t seg, uint64_t start, uint64_t count,
+                              void *d_out, uint64_t out_off);
+
+/* Point fetch: d_out[k] = value at row d_rows[k] of segment d_segs[k] — the intended semantics of
+ * SuccinctFetchRow (succinct.cpp:244-260; the reference implementation ignores row_id). */
+adac_status adac_fetch_rows(adac_layout *l, const uint64_t *d_words, const uint32_t *d_segs, const uint32_t *d_rows,
+                            uint64_t n, void *d_out);
+
+/* Fused scan + aggregate without materialising: d_sums[seg] = sum of decoded values (as unsigned T) mod 2^64.
+ * (what a SUM over a succinct column needs; reads packed bytes only.) */
+adac_status adac_scan_sum(adac_layout *l, const uint64_t *d_words, uint64_t *d_sums);
+
+/* Fused scan + equality filter: d_counts[seg] = number of rows whose decoded value == key (key given as the
+ * bit pattern of T zero-extended) — the `SELECT i FROM t1 WHERE i == k` look-ups of
+ * benchmark/micro/succinct/zipf_distribution.cpp:40-48 without materialising the column. */
+adac_status adac_scan_count_eq(adac_layout *l, const uint64_t *d_words, uint64_t key, uint64_t *d_counts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADACODEC_H */
