@@ -144,18 +144,18 @@ extern "C" adac_status adac_ctx_create(int device, void *external_stream, adac_c
 		}
 		c->owns_stream = true;
 	}
-	hipEventCreate(&c->ev_start);
-	hipEventCreate(&c->ev_stop);
+	(void)hipEventCreate(&c->ev_start);
+	(void)hipEventCreate(&c->ev_stop);
 	*out = c;
 	return ADAC_OK;
 }
 
 extern "C" void adac_ctx_destroy(adac_ctx *c) {
 	if (!c) return;
-	hipSetDevice(c->device);
-	if (c->ev_start) hipEventDestroy(c->ev_start);
-	if (c->ev_stop) hipEventDestroy(c->ev_stop);
-	if (c->owns_stream && c->stream) hipStreamDestroy(c->stream);
+	(void)hipSetDevice(c->device);
+	if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+	if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+	if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
 }
 
@@ -297,10 +297,10 @@ extern "C" adac_status adac_layout_create(adac_ctx *c, int type, const uint32_t 
 
 extern "C" void adac_layout_destroy(adac_layout *l) {
 	if (!l) return;
-	hipSetDevice(l->ctx->device);
-	if (l->d_descs) hipFree(l->d_descs);
-	if (l->d_tiles) hipFree(l->d_tiles);
-	if (l->d_minmax) hipFree(l->d_minmax);
+	(void)hipSetDevice(l->ctx->device);
+	if (l->d_descs) (void)hipFree(l->d_descs);
+	if (l->d_tiles) (void)hipFree(l->d_tiles);
+	if (l->d_minmax) (void)hipFree(l->d_minmax);
 	delete l;
 }
 

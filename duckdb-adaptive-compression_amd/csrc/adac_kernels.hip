@@ -284,8 +284,12 @@ __device__ __forceinline__ void load_chunk(const U *__restrict__ src /* element 
 	}
 }
 
-__device__ __forceinline__ bool row_valid(const uint64_t *__restrict__ validity, uint64_t elem) {
-	return validity == nullptr || ((validity[elem >> 6] >> (elem & 63)) & 1ull);
+// Validity bits of the K rows of one chunk.  A chunk starts at an element index that is a multiple of K and K
+// divides 64, so its K bits live in ONE word of the DuckDB validity mask: one 8-byte load per chunk.
+// Bit j of the result = row (chunk_elem + j) is valid.
+__device__ __forceinline__ uint32_t chunk_validity(const uint64_t *__restrict__ validity, uint64_t chunk_elem) {
+	if (validity == nullptr) return 0xffffffffu;
+	return (uint32_t)(validity[chunk_elem >> 6] >> (chunk_elem & 63));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -311,10 +315,11 @@ __global__ __launch_bounds__(kWorkgroup) void k_analyze(const adac_segment_desc 
 		const int32_t base = (int32_t)(c * K) - (int32_t)align;
 		U v[K];
 		load_chunk<U>(src, base, t.n, v);
+		const uint32_t vbits = chunk_validity(validity, (uint64_t)((int64_t)t.elem0 + base));
 #pragma unroll
 		for (int j = 0; j < K; j++) {
 			if ((uint32_t)(base + j) >= t.n) continue;
-			const bool valid = row_valid(validity, t.elem0 + (int64_t)(base + j));
+			const bool valid = (vbits >> j) & 1u;
 			uint64_t x;
 			if (rule == ADAC_RULE_APPEND) {
 				// succinct.cpp:286-287: uint64_t(sdata[i]); NULL rows do not take part
@@ -441,11 +446,12 @@ __global__ __launch_bounds__(kWorkgroup) void k_pack(const adac_segment_desc *__
 		const int32_t base = (int32_t)(c * K) - (int32_t)align;
 		U v[K];
 		load_chunk<U>(src, base, t.n, v);
+		const uint32_t vbits = chunk_validity(validity, (uint64_t)((int64_t)t.elem0 + base));
 #pragma unroll
 		for (int j = 0; j < K; j++) {
 			const uint32_t row = (uint32_t)(base + j);
 			if (row >= t.n) continue;
-			const bool valid = row_valid(validity, t.elem0 + row);
+			const bool valid = (vbits >> j) & 1u;
 			const U x = valid ? v[j] : (U)null_bits;
 			delta[row] = (U)(x - (U)sub) & wmask; // low w bits of (x - min): w <= 8*sizeof(U)
 		}

@@ -1,0 +1,327 @@
+"""GPU parity tests: the HIP path, called through the C ABI of libadacodec.so, against the CPU oracle on the
+same seeded inputs (bit-exact: this is integer / bit work) and against the committed known answers.
+Run on the MI355X box with `pytest -m gpu`."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ALL_DTYPES = [np.uint8, np.int8, np.uint16, np.int16, np.uint32, np.int32, np.uint64, np.int64]
+U64 = 0xFFFFFFFFFFFFFFFF
+
+
+def make_values(rng, dtype, n, bits, base=None):
+    """n values of `dtype` whose range (max - min) needs exactly `bits` bits (for n >= 2)."""
+    dtype = np.dtype(dtype)
+    tb = 8 * dtype.itemsize
+    bits = min(bits, tb)
+    top = 2 ** bits
+    span = rng.integers(0, top, size=n, dtype=np.uint64)
+    if n >= 2:  # pin both ends so the width is predictable
+        i0, i1 = rng.choice(n, size=2, replace=False)
+        span[i0] = 0
+        span[i1] = top - 1
+    if base is None:
+        hi = 2 ** tb - top
+        base = int(rng.integers(0, hi + 1, dtype=np.uint64)) if hi > 0 else 0
+    vals = (span + np.uint64(base)) & np.uint64(2 ** tb - 1)
+    return vals.astype(np.dtype("u%d" % dtype.itemsize)).view(dtype)
+
+
+def oracle_encode(orc, seg_vals, rule, padded, validity=None, val_offs=None):
+    """Per segment: (min, max, width, packed?, words) exactly as the reference's two encode paths."""
+    out = []
+    for i, v in enumerate(seg_vals):
+        tb = 8 * v.dtype.itemsize
+        vb0 = 0 if val_offs is None else int(val_offs[i])
+        mn, mx = orc.analyze_flat(v, rule, validity, vb0)
+        w = (orc.width_from_succinct if rule == 0 else orc.width_from_uncompressed)(mn, mx, padded)
+        packed = tb > w
+        if not packed:
+            w = tb
+        words = orc.pack_flat(v, mn if packed else U64, w, validity, vb0)
+        out.append((mn, mx, w, packed, words))
+    return out
+
+
+def run_encode_decode(adac, orc, ctx, dtype, counts, seg_vals, rule=0, padded=False, validity=None, val_offs=None):
+    dtype = np.dtype(dtype)
+    lay = adac.Layout(ctx, dtype, counts, val_offs)
+    span = max(lay.value_span, 1)
+    host_vals = np.zeros(span, dtype=dtype)
+    offs = np.cumsum(np.concatenate([[0], counts[:-1]]).astype(np.uint64)) if val_offs is None else val_offs
+    for v, o in zip(seg_vals, offs):
+        host_vals[int(o):int(o) + len(v)] = v
+    d_vals = ctx.upload(host_vals)
+    d_valid = None if validity is None else ctx.upload(validity)
+    d_words = ctx.alloc(lay.max_arena_words * 8 + 16).zero()
+    lay.encode(d_vals, d_words, d_valid, rule, padded)
+    descs = lay.get_descs()
+    mm = lay.get_minmax()
+    exp = oracle_encode(orc, seg_vals, rule, padded, validity, offs)
+    words_all = d_words.download(np.uint64, lay.max_arena_words)
+    woff = 0
+    for s, (mn, mx, w, packed, words) in enumerate(exp):
+        d = descs[s]
+        assert int(d["count"]) == len(seg_vals[s])
+        if len(seg_vals[s]):
+            assert (int(mm[s, 0]), int(mm[s, 1])) == (mn, mx), "min/max of segment %d" % s
+        assert int(d["width"]) == w, "width of segment %d" % s
+        assert bool(d["flags"] & adac.SEG_PACKED) == packed
+        assert int(d["word_off"]) == woff and woff % 16 == 0
+        if packed:
+            assert int(d["min"]) == mn
+        got = words_all[woff:woff + len(words)]
+        assert np.array_equal(got, words), "packed words of segment %d (w=%d)" % (s, w)
+        assert adac.size_in_bytes(len(seg_vals[s]), w) == orc.size_in_bytes(len(seg_vals[s]) * w)
+        woff += adac.arena_words(len(seg_vals[s]), w)
+    # decode
+    d_out = ctx.alloc(span * dtype.itemsize + 16)
+    ctx_fill = np.full(span, 0x5A, dtype=np.uint8).repeat(dtype.itemsize).view(dtype)[:span]
+    d_out.upload(ctx_fill)
+    lay.unpack(d_words, d_out)
+    ctx.sync()
+    out = d_out.download(dtype, span)
+    for s, (mn, mx, w, packed, words) in enumerate(exp):
+        o = int(offs[s])
+        n = len(seg_vals[s])
+        add = mn if (packed and mn != U64) else 0
+        ref = orc.unpack_flat(words, 0, n, w, add, dtype)
+        assert np.array_equal(out[o:o + n], ref), "decode of segment %d (w=%d)" % (s, w)
+        if validity is None:
+            assert np.array_equal(out[o:o + n], seg_vals[s]), "round trip of segment %d" % s
+    return lay, d_words, d_out, descs, out
+
+
+@pytest.mark.parametrize("dtype", ALL_DTYPES)
+def test_encode_decode_all_types(adac, oracle, gpu_ctx, dtype):
+    rng = np.random.default_rng(1234 + np.dtype(dtype).itemsize)
+    tb = 8 * np.dtype(dtype).itemsize
+    tile = adac.tile_values(dtype)
+    counts = np.array([1, 63, 64, 65, 2047, 2048, 2049, tile - 1, tile, tile + 1, 3 * tile + 17, 5],
+                      dtype=np.uint32)
+    bits = [1, 2, 3, 5, 7, 8, 9, 13, 16, 17, 24, 31, 32, 33, 47, 63, 64]
+    seg_vals = [make_values(rng, dtype, int(c), bits[i % len(bits)] if bits[i % len(bits)] <= tb else tb - 1)
+                for i, c in enumerate(counts)]
+    for rule in (adac.RULE_APPEND, adac.RULE_RECOMPACT):
+        for padded in (False, True):
+            run_encode_decode(adac, oracle, gpu_ctx, dtype, counts, seg_vals, rule, padded)
+
+
+@pytest.mark.parametrize("dtype", [np.uint64, np.uint32, np.uint16, np.uint8])
+def test_every_width(adac, oracle, gpu_ctx, dtype):
+    """Every width 1..8*sizeof(T): ragged counts straddling tile and word boundaries."""
+    rng = np.random.default_rng(99)
+    tb = 8 * np.dtype(dtype).itemsize
+    tile = adac.tile_values(dtype)
+    counts, seg_vals = [], []
+    for w in range(1, tb + 1):
+        n = int(rng.integers(2, 2 * tile + 100))
+        counts.append(n)
+        seg_vals.append(make_values(rng, dtype, n, w))
+    counts = np.array(counts, dtype=np.uint32)
+    lay, d_words, d_out, descs, _ = run_encode_decode(adac, oracle, gpu_ctx, dtype, counts, seg_vals)
+    widths = descs["width"].tolist()
+    assert widths[:tb - 1] == list(range(1, tb))  # w == tb cannot shrink: stays unpacked at tb
+    assert widths[tb - 1] == tb and not (descs["flags"][tb - 1] & adac.SEG_PACKED)
+
+
+def test_signed_and_mixed_sign(adac, oracle, gpu_ctx):
+    """Sign-extended min/max of the append path (succinct.cpp:286-287): all-negative segments pack, mixed-sign
+    segments cannot (range spans 2^64) and must still round-trip (the reference does not: SURVEY.md §4-1)."""
+    rng = np.random.default_rng(7)
+    for dtype in (np.int8, np.int16, np.int32, np.int64):
+        info = np.iinfo(dtype)
+        neg = rng.integers(max(info.min, -1000), -1, size=5000).astype(dtype)
+        mixed = rng.integers(-100, 100, size=5000).astype(dtype)
+        extremes = np.array([info.min, info.max, 0, -1, 1] * 100, dtype=dtype)
+        counts = np.array([len(neg), len(mixed), len(extremes)], dtype=np.uint32)
+        _, _, _, descs, _ = run_encode_decode(adac, oracle, gpu_ctx, dtype, counts, [neg, mixed, extremes],
+                                              adac.RULE_APPEND)
+        assert descs["flags"][0] & adac.SEG_PACKED
+        assert not (descs["flags"][1] & adac.SEG_PACKED)
+        # the recompaction path sees zero-extended raw values
+        run_encode_decode(adac, oracle, gpu_ctx, dtype, counts, [neg, mixed, extremes], adac.RULE_RECOMPACT)
+
+
+def test_nulls_validity_mask(adac, oracle, gpu_ctx):
+    """NULL rows: excluded from min/max on the append path, stored as NullValue<T> - min
+    (succinct.cpp:276-292); included as NullValue<T> on the recompaction path."""
+    rng = np.random.default_rng(11)
+    for dtype in (np.uint32, np.int32, np.uint64, np.int16):
+        counts = np.array([3000, 70, 9000, 64], dtype=np.uint32)
+        seg_vals = [make_values(rng, dtype, int(c), 11, base=5000) for c in counts]
+        total = int(counts.sum())
+        valid_bits = rng.random(total) > 0.3
+        valid_bits[3000:3070] = False  # an all-NULL segment: min stays UINT64_MAX, nothing subtracted
+        validity = np.packbits(valid_bits, bitorder="little")
+        validity = np.concatenate([validity, np.zeros((-len(validity)) % 8 + 8, dtype=np.uint8)]).view(np.uint64)
+        for rule in (adac.RULE_APPEND, adac.RULE_RECOMPACT):
+            _, _, _, descs, out = run_encode_decode(adac, oracle, gpu_ctx, dtype, counts, seg_vals, rule,
+                                                    validity=validity)
+            flat = np.concatenate(seg_vals)
+            if rule == adac.RULE_APPEND:
+                assert int(descs["min"][1]) == U64
+                ok = valid_bits.copy()
+                ok[3000:3070] = False
+                assert np.array_equal(out[:total][ok], flat[ok])
+
+
+def test_constant_and_empty_segments(adac, oracle, gpu_ctx):
+    dtype = np.uint32
+    counts = np.array([0, 100, 0, 4096, 1, 0], dtype=np.uint32)
+    seg_vals = [np.zeros(0, dtype), np.full(100, 42, dtype), np.zeros(0, dtype), np.full(4096, 7, dtype),
+                np.array([123456], dtype), np.zeros(0, dtype)]
+    _, _, _, d_app, _ = run_encode_decode(adac, oracle, gpu_ctx, dtype, counts, seg_vals, adac.RULE_APPEND)
+    assert d_app["width"].tolist()[1] == 1 and d_app["width"].tolist()[3] == 1   # hi(0)+1
+    _, _, _, d_rec, _ = run_encode_decode(adac, oracle, gpu_ctx, dtype, counts, seg_vals, adac.RULE_RECOMPACT)
+    assert d_rec["width"].tolist()[1] == 6 and d_rec["width"].tolist()[3] == 3   # max not reduced when max == min
+
+
+def test_unaligned_value_offsets(adac, oracle, gpu_ctx):
+    """Segments placed at arbitrary element offsets: every 16-byte store/load stays aligned internally."""
+    rng = np.random.default_rng(5)
+    for dtype in (np.uint8, np.uint16, np.uint32, np.uint64):
+        counts = np.array([1000, 37, 5000, 2048, 1], dtype=np.uint32)
+        gaps = [3, 1, 7, 5, 2]
+        offs, run = [], 0
+        for c, g in zip(counts, gaps):
+            run += g
+            offs.append(run)
+            run += int(c)
+        seg_vals = [make_values(rng, dtype, int(c), 6) for c in counts]
+        run_encode_decode(adac, oracle, gpu_ctx, dtype, counts, seg_vals, val_offs=np.array(offs, dtype=np.uint64))
+
+
+def test_known_answers_on_gpu(adac, oracle, gpu_ctx, golden):
+    """K1..K6 of SURVEY.md §8c through the device encode: identical min, width and packed words."""
+    for k in golden["sdsl"]:
+        dtype = np.dtype(k["dtype"])
+        vals = np.array(k["values"]).astype(dtype)
+        counts = np.array([len(vals)], dtype=np.uint32)
+        lay = adac.Layout(gpu_ctx, dtype, counts)
+        d_vals = gpu_ctx.upload(vals)
+        d_words = gpu_ctx.alloc(lay.max_arena_words * 8).zero()
+        lay.encode(d_vals, d_words, None, adac.RULE_APPEND, k["padded"])
+        d = lay.get_descs()[0]
+        assert int(d["min"]) == int(k["min"], 16)
+        assert int(d["width"]) == k["width"]
+        nw = adac.packed_words(len(vals), k["width"])
+        assert nw * 64 >= k["bit_size"] and adac.size_in_bytes(len(vals), k["width"]) == k["size_in_bytes"]
+        got = d_words.download(np.uint64, nw)
+        assert [int(x) for x in got] == [int(x, 16) for x in k["words"]]
+        d_out = gpu_ctx.alloc(64)
+        lay.unpack(d_words, d_out)
+        assert d_out.download(dtype, len(vals)).tolist() == k["values"]
+
+
+def test_decode_of_oracle_packed_segments(adac, oracle, gpu_ctx):
+    """Decode-only entry: descriptors + words produced elsewhere (here: by the oracle's segment model, i.e.
+    Append + Compact as the reference runs them) uploaded with adac_layout_set_descs."""
+    rng = np.random.default_rng(21)
+    dtype = np.dtype(np.uint64)
+    segs, counts = [], []
+    for n, bits in [(32767, 32), (2048, 11), (22531, 17), (16386, 40), (100, 64)]:
+        v = make_values(rng, dtype, n, bits)
+        s = oracle.Segment(dtype, segment_size=max(n, 2048) * 8)
+        for off in range(0, n, 2048):
+            s.append(v, offset=off, count=min(2048, n - off))
+        s.compact()
+        segs.append((s, v))
+        counts.append(n)
+    counts = np.array(counts, dtype=np.uint32)
+    lay = adac.Layout(gpu_ctx, dtype, counts)
+    descs = np.zeros(len(segs), dtype=adac.SEGMENT_DESC_DTYPE)
+    arena, woff, voff = [], 0, 0
+    for i, (s, v) in enumerate(segs):
+        w = s.width
+        descs[i] = (woff, voff, s.min_factor, len(v), w, adac.SEG_PACKED if w < 64 else 0, 0)
+        fp = adac.arena_words(len(v), w)
+        buf = np.zeros(fp, dtype=np.uint64)
+        words = s.words[:adac.packed_words(len(v), w)]
+        buf[:len(words)] = words
+        arena.append(buf)
+        woff += fp
+        voff += len(v)
+    lay.set_descs(descs)
+    d_words = gpu_ctx.upload(np.concatenate(arena))
+    d_out = gpu_ctx.alloc(int(counts.sum()) * 8)
+    lay.unpack(d_words, d_out)
+    out = d_out.download(dtype, int(counts.sum()))
+    assert np.array_equal(out, np.concatenate([v for _, v in segs]))
+
+
+def test_scan_vector_and_scan_partial_ranges(adac, oracle, gpu_ctx):
+    """adac_unpack_range = the scan_vector / scan_partial slots: 2048-row vectors, ragged tails, arbitrary
+    starts and result offsets (succinct.cpp:123-144,232-240)."""
+    rng = np.random.default_rng(3)
+    for dtype, bits in ((np.uint64, 27), (np.uint32, 13), (np.uint16, 5), (np.uint8, 3), (np.uint64, 40)):
+        dtype = np.dtype(dtype)
+        n = 32767 if dtype.itemsize == 8 else 65534
+        counts = np.array([2048, n], dtype=np.uint32)
+        seg_vals = [make_values(rng, dtype, int(c), bits) for c in counts]
+        lay, d_words, _, _, _ = run_encode_decode(adac, oracle, gpu_ctx, dtype, counts, seg_vals)
+        cases = [(1, 0, 2048, 0), (1, 2048, 2048, 0), (1, n - n % 2048, n % 2048, 0), (1, 1, 1, 0),
+                 (1, 12345, 4097, 3), (0, 5, 100, 1), (1, 0, n, 0), (1, n - 1, 1, 7), (1, 777, 0, 0)]
+        for seg, start, cnt, out_off in cases:
+            d_out = gpu_ctx.alloc((cnt + out_off + 16) * dtype.itemsize)
+            d_out.upload(np.full(cnt + out_off + 16, 0x77, dtype=dtype))
+            lay.unpack_range(d_words, seg, start, cnt, d_out, out_off)
+            got = d_out.download(dtype, cnt + out_off + 16)
+            assert np.array_equal(got[out_off:out_off + cnt], seg_vals[seg][start:start + cnt])
+            assert np.all(got[:out_off] == 0x77) and np.all(got[out_off + cnt:] == 0x77)  # nothing else written
+        with pytest.raises(adac.AdacError):
+            lay.unpack_range(d_words, 1, n - 5, 10, d_out, 0)
+        with pytest.raises(adac.AdacError):
+            lay.unpack_range(d_words, 2, 0, 1, d_out, 0)
+
+
+def test_fetch_rows(adac, oracle, gpu_ctx):
+    rng = np.random.default_rng(8)
+    for dtype, bits in ((np.uint64, 33), (np.int32, 9), (np.uint16, 16), (np.uint8, 2)):
+        dtype = np.dtype(dtype)
+        counts = np.array([5000, 1, 2048, 30000], dtype=np.uint32)
+        seg_vals = [make_values(rng, dtype, int(c), bits) for c in counts]
+        lay, d_words, _, _, _ = run_encode_decode(adac, oracle, gpu_ctx, dtype, counts, seg_vals)
+        k = 4000
+        segs = rng.integers(0, len(counts), size=k).astype(np.uint32)
+        rows = (rng.random(k) * counts[segs]).astype(np.uint32)
+        d_out = gpu_ctx.alloc(k * dtype.itemsize)
+        lay.fetch_rows(d_words, gpu_ctx.upload(segs), gpu_ctx.upload(rows), k, d_out)
+        got = d_out.download(dtype, k)
+        exp = np.array([seg_vals[s][r] for s, r in zip(segs, rows)], dtype=dtype)
+        assert np.array_equal(got, exp)
+
+
+def test_fused_scan_aggregates(adac, oracle, gpu_ctx):
+    rng = np.random.default_rng(13)
+    for dtype, bits in ((np.uint64, 32), (np.uint32, 20), (np.int16, 7), (np.uint8, 4), (np.int64, 50)):
+        dtype = np.dtype(dtype)
+        counts = np.array([40000, 2048, 1, 12345, 0, 65534 if dtype.itemsize < 8 else 32767], dtype=np.uint32)
+        seg_vals = [make_values(rng, dtype, int(c), bits) for c in counts]
+        lay, d_words, _, _, _ = run_encode_decode(adac, oracle, gpu_ctx, dtype, counts, seg_vals)
+        d_res = gpu_ctx.alloc(len(counts) * 8)
+        lay.scan_sum(d_words, d_res)
+        sums = d_res.download(np.uint64, len(counts))
+        udt = np.dtype("u%d" % dtype.itemsize)
+        exp = [int(v.view(udt).astype(np.uint64).sum(dtype=np.uint64)) for v in seg_vals]
+        assert sums.tolist() == exp
+        key_val = seg_vals[0][17]
+        key = int(np.array([key_val]).view(udt)[0])
+        lay.scan_count_eq(d_words, key, d_res)
+        cnts = d_res.download(np.uint64, len(counts))
+        assert cnts.tolist() == [int((v == key_val).sum()) for v in seg_vals]
+
+
+def test_argument_errors(adac, gpu_ctx):
+    with pytest.raises(adac.AdacError) as e:
+        adac.Layout(gpu_ctx, np.float32, [1])
+    assert e.value.status == 2  # unsupported type, like InternalException in SuccinctFun::GetFunction
+    lay = adac.Layout(gpu_ctx, np.uint32, np.array([10], dtype=np.uint32))
+    buf = gpu_ctx.alloc(4096)
+    with pytest.raises(adac.AdacError):
+        lay.unpack(buf.ptr + 4, buf)  # misaligned arena
+    bad = np.zeros(1, dtype=adac.SEGMENT_DESC_DTYPE)
+    bad[0] = (8, 0, 0, 10, 5, 1, 0)  # word_off not a multiple of 16
+    with pytest.raises(adac.AdacError):
+        lay.set_descs(bad)
