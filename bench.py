@@ -1,0 +1,369 @@
+#!/usr/bin/env python3
+"""bench.py — decoded values/s + achieved HBM GB/s of the succinct column codec on MI355X.
+
+Metric (BASELINE.json): decoded values/sec + achieved HBM GB/s, Zipf uint64 column, 1/2/4/8 GPU.
+Workload at N=1 (config C2): 100 M-row uint64 column, values Zipf(n = 2^32-1, s = 1.0) drawn with the
+reference's rejection-inversion sampler on mt19937 (seed 42 + rank), cut into segments the way the reference's
+Appender does (2048 / 32767 / ... rows), encoded on the device (analyze + plan + pack, timed separately) and
+then fully scanned.  One STEP = one full scan: adac_unpack over every segment of the rank's column (the
+whole-column form of SuccinctScanPartial, src/storage/compression/succinct.cpp:123-144), inputs and outputs
+resident in HBM.  N > 1: one process per GPU, each rank owns its own 100 M-row shard of segments (per-GPU
+segment pools, weak scaling, no data-path collective); value = total rows decoded by all ranks / max-over-ranks
+time.
+
+One JSON line on rank 0.  Extra objects: "roofline" (dominant kernel k_unpack, algorithmic bytes / HIP-event
+launch time vs the 8 TB/s HBM peak), "cpu_baseline" (the oracle's port of the reference scan loop on the host
+cores, same packed words), "encode", "fused_scan", "sweep".
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PKG = "duckdb-adaptive-compression_amd"
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable copy)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def algorithmic_bytes(descs, type_size):
+    """w/8 read (as whole packed words) + sizeof(T) written per value + 32 B descriptor/segment."""
+    counts = descs["count"].astype(np.uint64)
+    widths = descs["width"].astype(np.uint64)
+    read = int((((counts * widths + np.uint64(63)) >> np.uint64(6)) << np.uint64(3)).sum())
+    write = int(counts.sum()) * type_size
+    meta = 32 * len(descs)
+    return read, write, meta
+
+
+class DeviceColumn:
+    """One rank's shard: raw values, packed arena and decoded output resident in HBM."""
+
+    def __init__(self, adac, torch, ctx, vals, counts, dtype):
+        self.adac, self.torch, self.ctx = adac, torch, ctx
+        self.dtype = np.dtype(dtype)
+        self.n = len(vals)
+        self.layout = adac.Layout(ctx, self.dtype, counts)
+        dev = "cuda:%d" % ctx.device
+        signed = np.dtype("i%d" % self.dtype.itemsize)
+        tdt = {1: torch.int8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[self.dtype.itemsize]
+        self.d_vals = torch.from_numpy(vals.view(signed)).to(dev)
+        self.d_words = torch.zeros(self.layout.max_arena_words + 16, dtype=torch.int64, device=dev)
+        self.d_out = torch.empty(self.n + 16, dtype=tdt, device=dev)
+        torch.cuda.synchronize()  # allocations/fills ran on torch's stream; the codec uses its own
+        self.descs = None
+
+    def encode(self, rule, padded=False):
+        self.layout.encode(self.d_vals, self.d_words, None, rule, padded)
+
+    def unpack(self):
+        self.layout.unpack(self.d_words, self.d_out)
+
+    def fetch_descs(self):
+        self.descs = self.layout.get_descs()
+        return self.descs
+
+    def verify_roundtrip(self):
+        return bool(self.torch.equal(self.d_out[:self.n], self.d_vals))
+
+
+def time_launches(ctx, fn, reps):
+    """Average duration of one launch of fn over `reps` back-to-back launches, HIP events on the ctx stream."""
+    ctx.sync()
+    ctx.timer_start()
+    for _ in range(reps):
+        fn()
+    ms = ctx.timer_stop()
+    return ms / reps
+
+
+def cpu_baseline(orc, col, vals, seconds, threads):
+    """The oracle's port of the reference scan loop (per-value read_int + min add, 2048 rows per call) on the
+    host cores, over the same packed words the GPU produced; also proves at full size that the oracle decodes
+    the device-packed column back to the input."""
+    descs = col.descs
+    arena = col.d_words.cpu().numpy().view(np.uint64)
+    n = col.n
+    seg_words, adds = [], []
+    for d in descs:
+        wo, c, w = int(d["word_off"]), int(d["count"]), int(d["width"])
+        nw = (c * w + 63) // 64
+        seg_words.append(arena[wo:wo + nw + 1])
+        packed = bool(d["flags"] & 1) and int(d["min"]) != 0xFFFFFFFFFFFFFFFF
+        adds.append(int(d["min"]) if packed else 0)
+    counts = descs["count"].astype(np.uint64)
+    widths = descs["width"]
+    out_offs = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.uint64)
+    out = np.empty(n, dtype=col.dtype)
+
+    def run(th, nseg=None, with_copy=False):
+        k = len(seg_words) if nseg is None else nseg
+        t0 = time.perf_counter()
+        orc.scan_segments_mt(seg_words[:k], counts[:k], widths[:k], adds[:k], out_offs[:k], col.dtype, out,
+                             with_copy=with_copy, threads=th)
+        return time.perf_counter() - t0, int(counts[:k].sum())
+
+    t, rows = run(threads)  # warm + verification pass
+    ok = bool(np.array_equal(out, vals))
+    reps, total_t = 0, 0.0
+    while total_t < seconds and reps < 200:
+        t, rows = run(threads)
+        total_t += t
+        reps += 1
+    mt_rate = rows * reps / total_t
+    # single thread on a bounded sample of segments: copy-free and faithful (whole-vector copy per call)
+    k = min(len(seg_words), 96)
+    t1, r1 = run(1, k)
+    t1, r1 = run(1, k)
+    t2, r2 = run(1, min(k, 24), with_copy=True)
+    return {
+        "value": mt_rate, "unit": "values/s", "cores": threads, "kind": "port",
+        "sample": "full column (%d rows, %d segments) x %d passes, copy-free scan loop, %d host threads, "
+                  "one contiguous segment range per thread" % (n, len(seg_words), reps, threads),
+        "single_thread_value": r1 / t1,
+        "single_thread_faithful_copy_value": r2 / t2,
+        "faithful_note": "faithful = with the reference's per-call deep copy of the segment's int_vector "
+                         "(succinct.cpp:127); sample = first %d segments" % min(k, 24),
+        "oracle_decodes_device_words_to_input": ok,
+    }
+
+
+def run_sweep(adac, torch, ctx, rows, steps):
+    """Decode + fused-scan throughput for uniformly distributed values at widths 8..32 (the north star's
+    '8-32-bit unpack' range), uint64 and uint32 outputs."""
+    out = []
+    rng = np.random.default_rng(7)
+    for dtype, widths in ((np.uint64, (8, 13, 16, 20, 24, 32)), (np.uint32, (8, 13, 16, 20, 24))):
+        dtype = np.dtype(dtype)
+        counts = adac.appender_segment_counts(rows, dtype.itemsize)
+        for w in widths:
+            vals = rng.integers(0, 2 ** w, size=rows, dtype=np.uint64).astype(dtype)
+            col = DeviceColumn(adac, torch, ctx, vals, counts, dtype)
+            col.encode(adac.RULE_APPEND)
+            col.unpack()
+            ctx.sync()
+            descs = col.fetch_descs()
+            assert col.verify_roundtrip()
+            rd, wr, meta = algorithmic_bytes(descs, dtype.itemsize)
+            ms = time_launches(ctx, col.unpack, steps)
+            d_sums = torch.zeros(len(counts), dtype=torch.int64, device=col.d_vals.device)
+            torch.cuda.synchronize()
+            col.layout.scan_sum(col.d_words, d_sums)
+            ms_sum = time_launches(ctx, lambda: col.layout.scan_sum(col.d_words, d_sums), steps)
+            out.append({
+                "dtype": "u%d" % (8 * dtype.itemsize), "width": w,
+                "widths_seen": sorted(set(descs["width"].tolist())),
+                "decode_values_per_s": rows / (ms * 1e-3),
+                "decode_total_GBps": (rd + wr + meta) / (ms * 1e-3) / 1e9,
+                "decode_read_GBps": rd / (ms * 1e-3) / 1e9,
+                "fused_sum_values_per_s": rows / (ms_sum * 1e-3),
+                "fused_sum_read_GBps": rd / (ms_sum * 1e-3) / 1e9,
+                "fused_sum_read_frac_of_peak": rd / (ms_sum * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            })
+            del col, d_sums
+            torch.cuda.empty_cache()
+    return out
+
+
+def plumbing_only(args, comm):
+    """CPU rehearsal of the N>1 control flow (rendezvous, barrier, max/sum reductions, rank-0 JSON) with NO
+    device work and NO codec work: used by the gloo world_size-2 test.  Never reports a throughput claim."""
+    sh = importlib.import_module(PKG + ".sharding")
+    adac = importlib.import_module(PKG)
+    counts = adac.appender_segment_counts(args.rows, 8)
+    lo, hi = sh.segment_range(len(counts) * comm.world, comm.rank, comm.world)
+    comm.barrier()
+    elapsed = comm.max(0.001 * (comm.rank + 1))
+    total_rows = comm.sum(int(counts.sum()))
+    nseg_total = comm.sum(hi - lo)
+    comm.barrier()
+    if comm.rank == 0:
+        print(json.dumps({"metric": "plumbing-only", "value": None, "n_gpus": comm.world, "data": "plumbing-only",
+                          "max_elapsed": elapsed, "total_rows": total_rows, "total_segments": nseg_total,
+                          "rows_per_rank": int(counts.sum())}), flush=True)
+    comm.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU")
+    ap.add_argument("--skew", type=float, default=1.0)
+    ap.add_argument("--domain", type=int, default=2 ** 32 - 1)
+    ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    ap.add_argument("--sweep-rows", type=int, default=50_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--backend", default=None)
+    ap.add_argument("--plumbing-only", action="store_true")
+    args = ap.parse_args()
+
+    sh = importlib.import_module(PKG + ".sharding")
+    rank, local_rank, world = sh.dist_env()
+    if args.plumbing_only:
+        return plumbing_only(args, sh.Comm(backend=args.backend or "gloo"))
+
+    import torch
+    adac = importlib.import_module(PKG)
+    if not os.path.exists(adac.LIB_PATH):
+        if rank == 0:
+            importlib.import_module("__graft_entry__").build()
+    wl = importlib.import_module(PKG + ".workload")
+    if not torch.cuda.is_available():
+        raise adac.AdacError(5, "bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    comm = sh.Comm(backend=args.backend, device=local_rank)
+    comm.barrier()
+    stream = torch.cuda.Stream(device=local_rank)
+    ctx = adac.Context(local_rank, stream.cuda_stream)
+
+    dtype = np.dtype(np.uint64)
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    gen_threads = max(1, min(32, ncpu // max(1, min(world, 8))))
+    t0 = time.perf_counter()
+    vals = wl.zipf_column(args.rows, dtype, domain=args.domain, skew=args.skew, seed=42 + rank, threads=gen_threads)
+    counts = adac.appender_segment_counts(args.rows, dtype.itemsize)
+    log("[rank %d] generated %d rows / %d segments in %.1f s" % (rank, args.rows, len(counts),
+                                                                time.perf_counter() - t0))
+    col = DeviceColumn(adac, torch, ctx, vals, counts, dtype)
+
+    # ---- encode (timed separately; not part of the step) ----
+    col.encode(adac.RULE_APPEND)
+    ctx.sync()
+    enc_ms = time_launches(ctx, lambda: col.encode(adac.RULE_APPEND), 5)
+    descs = col.fetch_descs()
+    rd, wr, meta = algorithmic_bytes(descs, dtype.itemsize)
+    wh = {}
+    for w, c in zip(descs["width"].tolist(), descs["count"].tolist()):
+        wh[w] = wh.get(w, 0) + c
+
+    # ---- correctness at full size (not timed): round trip + checksum ----
+    col.unpack()
+    ctx.sync()
+    roundtrip_ok = col.verify_roundtrip()
+    d_sums = torch.zeros(len(counts), dtype=torch.int64, device=col.d_vals.device)
+    torch.cuda.synchronize()
+    col.layout.scan_sum(col.d_words, d_sums)
+    ctx.sync()
+    checksum_ok = int(d_sums.sum().item()) & (2 ** 64 - 1) == int(vals.sum(dtype=np.uint64))
+    if not (roundtrip_ok and checksum_ok):
+        raise RuntimeError("parity failure at full size: roundtrip=%s checksum=%s" % (roundtrip_ok, checksum_ok))
+
+    # ---- the timed region: W warm-up scans, then exactly K scans between barriers ----
+    for _ in range(args.warmup):
+        col.unpack()
+    ctx.sync()
+    torch.cuda.synchronize()
+    comm.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    for _ in range(args.steps):
+        col.unpack()
+    ev_ms = ctx.timer_stop()  # HIP events on the stream k_unpack is launched on (synchronises)
+    torch.cuda.synchronize()
+    comm.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = comm.max(elapsed)
+    total_rows = comm.sum(args.rows)
+    value = total_rows * args.steps / elapsed
+    launch_ms = ev_ms / args.steps
+    launch_ms_max = comm.max(launch_ms)
+
+    result = {
+        "metric": "decoded values/sec + achieved HBM GB/s, Zipf uint64 column",
+        "value": value,
+        "unit": "values/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u64",
+        "data": "synthetic",
+        "config": {
+            "workload": "C2: %d-row uint64 Zipf(s=%.1f, n=%d) single column per GPU, mt19937 seed 42+rank, "
+                        "Appender segment layout, full scan (decode to HBM); encode timed separately"
+                        % (args.rows, args.skew, args.domain),
+            "rows_per_gpu": args.rows,
+            "segments_per_gpu": int(len(counts)),
+            "rows_by_width": {str(k): int(v) for k, v in sorted(wh.items())},
+            "sharding": "segments partitioned by id, one pool per GPU, no collective on the data path",
+        },
+        "achieved_HBM_GBps_aggregate": (rd + wr + meta) * world / (launch_ms_max * 1e-3) / 1e9,
+        "parity": {"roundtrip_full_size": roundtrip_ok, "checksum_full_size": checksum_ok},
+    }
+
+    # roofline of the dominant kernel (k_unpack<u64>) on this rank
+    ach = (rd + wr + meta) / (launch_ms * 1e-3) / 1e9
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_path):
+        try:
+            pmc = json.load(open(pmc_path))
+            if pmc.get("rows") == args.rows and pmc.get("kernel") == "k_unpack<u64>":
+                traffic = pmc.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    result["roofline"] = {
+        "kernel": "k_unpack<u64>", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+        "algorithmic_bytes_per_launch": rd + wr + meta, "read_bytes": rd, "write_bytes": wr,
+        "launch_ms": launch_ms,
+        "read_GBps": rd / (launch_ms * 1e-3) / 1e9, "read_frac_of_peak": rd / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+    }
+    result["encode"] = {
+        "values_per_s": args.rows / (enc_ms * 1e-3), "ms": enc_ms,
+        "algorithmic_GBps": (2 * wr + rd) / (enc_ms * 1e-3) / 1e9,
+        "note": "analyze + plan + pack, raw column read twice (min/max pass, pack pass)",
+    }
+
+    if world == 1 and rank == 0:
+        # fused scan+sum (no materialisation): the read-roofline variant
+        ms_sum = time_launches(ctx, lambda: col.layout.scan_sum(col.d_words, d_sums), args.steps)
+        result["fused_scan"] = {
+            "kernel": "k_scan_agg<u64,sum>", "values_per_s": args.rows / (ms_sum * 1e-3),
+            "read_GBps": rd / (ms_sum * 1e-3) / 1e9, "read_frac_of_peak": rd / (ms_sum * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        }
+        # measured device copy rate, for "fraction of achievable" next to "fraction of spec peak"
+        src = col.d_vals
+        dst = torch.empty_like(src)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(stream):
+            dst.copy_(src)
+            ms_copy = time_launches(ctx, lambda: dst.copy_(src), 10)
+        copy_gbps = 2 * src.numel() * 8 / (ms_copy * 1e-3) / 1e9
+        result["device_copy_GBps"] = copy_gbps
+        result["roofline"]["frac_of_measured_copy"] = ach / copy_gbps
+        del dst
+        if not args.no_cpu_baseline:
+            import oracle as orc
+            orc.build()
+            threads = ncpu
+            result["cpu_baseline"] = cpu_baseline(orc, col, vals, args.cpu_seconds, threads)
+        if not args.no_sweep:
+            del col.d_out
+            torch.cuda.empty_cache()
+            result["sweep"] = run_sweep(adac, torch, ctx, args.sweep_rows, max(5, args.steps // 2))
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    comm.close()
+
+
+if __name__ == "__main__":
+    main()
