@@ -197,12 +197,13 @@ def plumbing_only(args, comm):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU")
     ap.add_argument("--skew", type=float, default=1.0)
     ap.add_argument("--domain", type=int, default=2 ** 32 - 1)
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the CPU baseline (the box's CPU share per GPU)")
     ap.add_argument("--sweep-rows", type=int, default=50_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
@@ -242,7 +243,7 @@ def main():
     # ---- encode (timed separately; not part of the step) ----
     col.encode(adac.RULE_APPEND)
     ctx.sync()
-    enc_ms = time_launches(ctx, lambda: col.encode(adac.RULE_APPEND), 5)
+    enc_ms = time_launches(ctx, lambda: col.encode(adac.RULE_APPEND), 10)
     descs = col.fetch_descs()
     rd, wr, meta = algorithmic_bytes(descs, dtype.itemsize)
     wh = {}
@@ -353,12 +354,12 @@ def main():
         if not args.no_cpu_baseline:
             import oracle as orc
             orc.build()
-            threads = ncpu
+            threads = max(1, min(ncpu, args.cpu_threads))
             result["cpu_baseline"] = cpu_baseline(orc, col, vals, args.cpu_seconds, threads)
         if not args.no_sweep:
             del col.d_out
             torch.cuda.empty_cache()
-            result["sweep"] = run_sweep(adac, torch, ctx, args.sweep_rows, max(5, args.steps // 2))
+            result["sweep"] = run_sweep(adac, torch, ctx, args.sweep_rows, min(50, max(5, args.steps // 2)))
 
     if rank == 0:
         print(json.dumps(result), flush=True)
