@@ -209,6 +209,8 @@ def main():
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--backend", default=None)
     ap.add_argument("--plumbing-only", action="store_true")
+    ap.add_argument("--single-device-rehearsal", action="store_true",
+                    help="map every rank to cuda:0 (rehearse N>1 on a one-GPU box; use with --backend gloo)")
     args = ap.parse_args()
 
     sh = importlib.import_module(PKG + ".sharding")
@@ -224,6 +226,8 @@ def main():
     wl = importlib.import_module(PKG + ".workload")
     if not torch.cuda.is_available():
         raise adac.AdacError(5, "bench.py needs an MI355X (no CPU fallback)")
+    if args.single_device_rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     comm = sh.Comm(backend=args.backend, device=local_rank)
     comm.barrier()

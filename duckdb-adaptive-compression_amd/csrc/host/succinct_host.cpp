@@ -1,0 +1,780 @@
+// succinct_host.cpp — see succinct_host.hpp.  Device work goes through include/adacodec.h only; the host
+// side moves bytes (memcpy, NULL-slot fill) and keeps the reference's state machine and accounting.
+#include "succinct_host.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+
+#include "adacodec_host.h"
+
+namespace adacodec {
+
+static void Check(adac_status st, const char *what) {
+	if (st != ADAC_OK) {
+		std::string msg = std::string("adacodec: ") + what + ": " + adac_status_string(st);
+		if (st == ADAC_ERR_DEVICE) msg += std::string(" (") + adac_last_error() + ")";
+		throw InternalException(msg);
+	}
+}
+
+static bool IsSigned(PhysicalType t) {
+	return t == PhysicalType::INT8 || t == PhysicalType::INT16 || t == PhysicalType::INT32 || t == PhysicalType::INT64;
+}
+
+// NullValue<T>() = numeric_limits<T>::min() as the bit pattern of T (null_value.hpp:26-28)
+static uint64_t NullBits(PhysicalType t, idx_t type_size) {
+	return IsSigned(t) ? (1ull << (8 * type_size - 1)) : 0ull;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SegmentPool
+// ------------------------------------------------------------------------------------------------
+
+SegmentPool::SegmentPool(int device, size_t arena_bytes) {
+	Check(adac_ctx_create(device, nullptr, &ctx), "adac_ctx_create");
+	arena_words = ((arena_bytes / 8) + 15) & ~15ull;
+	if (arena_words < 16) arena_words = 16;
+	void *p = nullptr;
+	adac_status st = adac_dev_alloc(ctx, arena_words * 8, &p);
+	if (st != ADAC_OK) {
+		adac_ctx_destroy(ctx);
+		Check(st, "adac_dev_alloc(arena)");
+	}
+	d_arena = static_cast<uint64_t *>(p);
+	adac_dev_memset(ctx, d_arena, 0, arena_words * 8);
+	adac_ctx_sync(ctx);
+	free_list[0] = arena_words;
+}
+
+SegmentPool::~SegmentPool() {
+	if (d_staging) adac_dev_free(ctx, d_staging);
+	if (d_staging2) adac_dev_free(ctx, d_staging2);
+	if (d_arena) adac_dev_free(ctx, d_arena);
+	adac_ctx_destroy(ctx);
+}
+
+uint64_t SegmentPool::Allocate(uint64_t words) {
+	words = (words + 15) & ~15ull;
+	for (auto it = free_list.begin(); it != free_list.end(); ++it) {
+		if (it->second >= words) {
+			uint64_t off = it->first, len = it->second;
+			free_list.erase(it);
+			if (len > words) free_list[off + words] = len - words;
+			used_words += words;
+			return off;
+		}
+	}
+	throw InternalException("adacodec: segment pool arena exhausted");
+}
+
+void SegmentPool::Free(uint64_t off, uint64_t words) {
+	words = (words + 15) & ~15ull;
+	used_words -= words;
+	auto next = free_list.lower_bound(off);
+	if (next != free_list.begin()) {
+		auto prev = std::prev(next);
+		if (prev->first + prev->second == off) { // merge with the block before
+			off = prev->first;
+			words += prev->second;
+			free_list.erase(prev);
+		}
+	}
+	if (next != free_list.end() && off + words == next->first) { // and with the block after
+		words += next->second;
+		free_list.erase(next);
+	}
+	free_list[off] = words;
+}
+
+static void *Grow(adac_ctx *ctx, void *&buf, size_t &have, size_t want) {
+	if (want > have) {
+		if (buf) adac_dev_free(ctx, buf);
+		buf = nullptr;
+		size_t n = std::max(want, have * 2);
+		n = (n + 255) & ~size_t(255);
+		Check(adac_dev_alloc(ctx, n, &buf), "adac_dev_alloc(staging)");
+		have = n;
+	}
+	return buf;
+}
+
+void *SegmentPool::Staging(size_t bytes) {
+	return Grow(ctx, d_staging, staging_bytes, bytes + 64);
+}
+void *SegmentPool::Staging2(size_t bytes) {
+	return Grow(ctx, d_staging2, staging2_bytes, bytes + 64);
+}
+
+// A batch layout shared by the segments compacted together (one adac_layout, many segments).
+struct LayoutHandle {
+	adac_layout *layout = nullptr;
+	~LayoutHandle() {
+		if (layout) adac_layout_destroy(layout);
+	}
+};
+
+// per-segment side table (kept out of the header: it holds C-ABI handles)
+struct SegmentDeviceRef {
+	std::shared_ptr<LayoutHandle> layout;
+	uint64_t index = 0;
+};
+static std::mutex g_ref_lock;
+static std::unordered_map<const ColumnSegment *, SegmentDeviceRef> g_refs;
+
+static SegmentDeviceRef GetRef(const ColumnSegment *s) {
+	std::lock_guard<std::mutex> g(g_ref_lock);
+	auto it = g_refs.find(s);
+	return it == g_refs.end() ? SegmentDeviceRef() : it->second;
+}
+static void SetRef(const ColumnSegment *s, SegmentDeviceRef r) {
+	std::lock_guard<std::mutex> g(g_ref_lock);
+	g_refs[s] = std::move(r);
+}
+static void DropRef(const ColumnSegment *s) {
+	std::lock_guard<std::mutex> g(g_ref_lock);
+	g_refs.erase(s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// CompressionFunction tables
+// ------------------------------------------------------------------------------------------------
+
+static void CodecScanPartial(ColumnSegment &segment, ColumnScanState &state, idx_t scan_count, Vector &result,
+                             idx_t result_offset) {
+	// succinct.cpp:123-144 / fixed_size_uncompressed.cpp FixedSizeScanPartial
+	auto start = segment.GetRelativeIndex(state.row_index);
+	result.flat = true; // SetVectorType(FLAT_VECTOR)
+	segment.ScanRows(start, scan_count, result.data + result_offset * segment.type_size);
+}
+static void CodecScan(ColumnSegment &segment, ColumnScanState &state, idx_t scan_count, Vector &result) {
+	CodecScanPartial(segment, state, scan_count, result, 0); // succinct.cpp:232-240
+}
+static void CodecFetchRow(ColumnSegment &segment, ColumnFetchState &, row_t row_id, Vector &result, idx_t result_idx) {
+	// intended semantics of SuccinctFetchRow (succinct.cpp:244-260): one value at row_id
+	segment.ScanRows((idx_t)row_id, 1, result.data + result_idx * segment.type_size);
+}
+static void EmptySkip(ColumnSegment &, ColumnScanState &, idx_t) {
+}
+static idx_t CodecAppend(ColumnSegment &segment, UnifiedVectorFormat &data, idx_t offset, idx_t count) {
+	return segment.AppendRows(data, offset, count); // succinct.cpp:308-322 / FixedSizeAppend
+}
+static idx_t CodecFinalizeAppend(ColumnSegment &segment) {
+	return segment.count * segment.type_size; // succinct.cpp:324-330
+}
+
+bool SuccinctFun::TypeIsSupported(PhysicalType type) {
+	return adac_type_is_supported((int)type) != 0;
+}
+
+CompressionFunction SuccinctFun::GetFunction(PhysicalType data_type) {
+	if (!TypeIsSupported(data_type)) throw InternalException("Unsupported type for FixedSizeSuccinct::GetFunction");
+	return CompressionFunction {CompressionType::COMPRESSION_SUCCINCT, data_type, CodecScan, CodecScanPartial,
+	                            CodecFetchRow, EmptySkip, CodecAppend, CodecFinalizeAppend};
+}
+
+CompressionFunction UncompressedFun::GetFunction(PhysicalType data_type) {
+	if (!SuccinctFun::TypeIsSupported(data_type)) throw InternalException("Unsupported type for FixedSizeUncompressed");
+	return CompressionFunction {CompressionType::COMPRESSION_UNCOMPRESSED, data_type, CodecScan, CodecScanPartial,
+	                            CodecFetchRow, EmptySkip, CodecAppend, CodecFinalizeAppend};
+}
+
+// ------------------------------------------------------------------------------------------------
+// DatabaseInstance
+// ------------------------------------------------------------------------------------------------
+
+DatabaseInstance::DatabaseInstance(int device, const DBConfig &config_p, size_t arena_bytes)
+    : config(config_p), pool(device, arena_bytes), catalog(*this) {
+}
+
+const CompressionFunction *DatabaseInstance::GetCompressionFunction(CompressionType type, PhysicalType data_type) {
+	std::lock_guard<std::mutex> g(fn_lock);
+	auto key = std::make_pair((uint8_t)type, (uint8_t)data_type);
+	auto it = functions.find(key);
+	if (it == functions.end()) {
+		CompressionFunction fn = type == CompressionType::COMPRESSION_SUCCINCT ? SuccinctFun::GetFunction(data_type)
+		                                                                       : UncompressedFun::GetFunction(data_type);
+		it = functions.emplace(key, fn).first;
+	}
+	return &it->second;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ColumnSegment
+// ------------------------------------------------------------------------------------------------
+
+std::unique_ptr<ColumnSegment> ColumnSegment::CreateTransientSegment(DatabaseInstance &db, PhysicalType type,
+                                                                     idx_t start, idx_t segment_size) {
+	// column_segment.cpp:45-82
+	if (!SuccinctFun::TypeIsSupported(type)) throw InternalException("Unsupported type for the succinct codec");
+	auto &config = db.config;
+	const CompressionFunction *function;
+	bool succinct_possible;
+	if (config.succinct_enabled && !config.adaptive_succinct_compression_enabled) {
+		succinct_possible = true;
+		function = db.GetCompressionFunction(CompressionType::COMPRESSION_SUCCINCT, type);
+	} else {
+		succinct_possible = config.succinct_enabled;
+		function = db.GetCompressionFunction(CompressionType::COMPRESSION_UNCOMPRESSED, type);
+	}
+	return std::unique_ptr<ColumnSegment>(new ColumnSegment(db, type, start, segment_size, function, succinct_possible,
+	                                                        config.adaptive_succinct_compression_enabled));
+}
+
+ColumnSegment::ColumnSegment(DatabaseInstance &db_p, PhysicalType type_p, idx_t start_p, idx_t segment_size_p,
+                             const CompressionFunction *fn, bool succinct_possible_p, bool background_p)
+    : db(db_p), type(type_p), type_size(adac_type_size((int)type_p)), start(start_p), function(fn),
+      succinct_possible(succinct_possible_p), segment_size(segment_size_p), background_compaction_enabled(background_p) {
+	raw.assign(segment_size, 0);
+	if (function->type == CompressionType::COMPRESSION_SUCCINCT) {
+		// column_segment.cpp:101-105: succinct_vec.width(8*type_size); resize(segment_size / type_size)
+		vec_width = (uint8_t)(8 * type_size);
+		vec_slots = segment_size / type_size;
+		appended_via_succinct = true;
+		db.data_size += (int64_t)adac_size_in_bytes(vec_slots, vec_width);
+	} else {
+		vec_width = 64;
+		vec_slots = 0;
+		db.data_size += (int64_t)segment_size; // AddOnlyToDataSize (column_segment.cpp:74)
+	}
+	db.catalog.AddColumnSegment(this);
+}
+
+ColumnSegment::~ColumnSegment() {
+	db.catalog.RemoveColumnSegment(this);
+	if (packed_on_device) {
+		std::lock_guard<std::mutex> g(db.pool.lock);
+		db.pool.Free(word_off, arena_words);
+	}
+	DropRef(this);
+}
+
+idx_t ColumnSegment::GetDataSize() const {
+	// column_segment.cpp:204-214
+	if (!is_data_segment) return 0;
+	if (function->type == CompressionType::COMPRESSION_SUCCINCT) return adac_size_in_bytes(vec_slots, vec_width);
+	return segment_size;
+}
+
+idx_t ColumnSegment::SuccinctSize() const {
+	return function->type == CompressionType::COMPRESSION_SUCCINCT ? adac_size_in_bytes(vec_slots, vec_width) : 0;
+}
+
+void ColumnSegment::Scan(ColumnScanState &state, idx_t scan_count, Vector &result, idx_t result_offset,
+                         bool entire_vector) {
+	// column_segment.cpp:137-188
+	db.catalog.AddReadAccess(this);
+	if (!compacted && !background_compaction_enabled) Compact();
+	{
+		std::lock_guard<std::mutex> g(bit_compression_lock);
+		force_reinitializing_scan_state = false; // scan states carry nothing in this codec
+	}
+	if (entire_vector) {
+		function->scan_vector(*this, state, scan_count, result);
+	} else {
+		function->scan_partial(*this, state, scan_count, result, result_offset);
+	}
+}
+
+void ColumnSegment::Skip(ColumnScanState &state) {
+	function->skip(*this, state, 0);
+}
+
+void ColumnSegment::FetchRow(ColumnFetchState &state, row_t row_id, Vector &result, idx_t result_idx) {
+	function->fetch_row(*this, state, row_id - (row_t)start, result, result_idx); // column_segment.cpp:193-195
+}
+
+void ColumnSegment::ScanRows(idx_t start_row, idx_t scan_count, data_ptr_t target) {
+	if (start_row > count || scan_count > count - start_row) throw InternalException("scan beyond the segment");
+	if (scan_count == 0) return;
+	std::lock_guard<std::mutex> g(bit_compression_lock);
+	if (function->type == CompressionType::COMPRESSION_SUCCINCT && packed_on_device) {
+		SegmentDeviceRef ref = GetRef(this);
+		std::lock_guard<std::mutex> pg(db.pool.lock);
+		void *d_out = db.pool.Staging(scan_count * type_size);
+		Check(adac_unpack_range(ref.layout->layout, db.pool.d_arena, ref.index, start_row, scan_count, d_out, 0),
+		      "adac_unpack_range");
+		Check(adac_memcpy_d2h(db.pool.ctx, target, d_out, scan_count * type_size), "adac_memcpy_d2h");
+	} else {
+		// unpacked slots / uncompressed block: the bytes ARE the values (no min add: SURVEY.md §8a (iii))
+		std::memcpy(target, raw.data() + start_row * type_size, scan_count * type_size);
+	}
+}
+
+idx_t ColumnSegment::AppendRows(UnifiedVectorFormat &data, idx_t offset, idx_t append_count) {
+	// SuccinctAppend (succinct.cpp:308-322) / FixedSizeAppend: no arithmetic here — the running min/max of
+	// SuccinctAppendLoop is produced by adac_analyze when the segment compacts.
+	idx_t max_tuple_count = segment_size / type_size;
+	idx_t copy_count = std::min<idx_t>(append_count, max_tuple_count - count);
+	const bool track_validity = function->type == CompressionType::COMPRESSION_SUCCINCT;
+	const uint64_t null_bits = NullBits(type, type_size);
+	if (track_validity && validity.empty()) validity.assign((max_tuple_count + 63) / 64 + 1, ~0ull);
+	for (idx_t i = 0; i < copy_count; i++) {
+		idx_t source_idx = data.sel ? data.sel[offset + i] : offset + i;
+		idx_t target_idx = count + i;
+		bool valid = !data.validity || ((data.validity[source_idx >> 6] >> (source_idx & 63)) & 1);
+		if (valid) {
+			std::memcpy(raw.data() + target_idx * type_size, data.data + source_idx * type_size, type_size);
+		} else {
+			std::memcpy(raw.data() + target_idx * type_size, &null_bits, type_size); // NullValue<T>()
+			if (track_validity) {
+				validity[target_idx >> 6] &= ~(1ull << (target_idx & 63));
+				any_null = true;
+			}
+		}
+	}
+	count += copy_count;
+	return copy_count;
+}
+
+idx_t ColumnSegment::Append(UnifiedVectorFormat &append_data, idx_t offset, idx_t append_count) {
+	// column_segment.cpp:247-271
+	bool uncompacted = false;
+	if (IsBitCompressed()) {
+		Uncompact();
+		uncompacted = true;
+	}
+	idx_t copy_count = function->append(*this, append_data, offset, append_count);
+	num_elements += append_count; // sic: the requested count
+	if (!compacted && !background_compaction_enabled && (num_elements >= vec_slots || uncompacted)) {
+		Compact();
+	}
+	return copy_count;
+}
+
+idx_t ColumnSegment::FinalizeAppend() {
+	return function->finalize_append(*this);
+}
+
+bool ColumnSegment::NeedsCompaction() const {
+	// column_segment.cpp:278-280
+	return !(compacted || !function || num_elements == 0 || !succinct_possible);
+}
+
+void ColumnSegment::Compact() {
+	std::vector<ColumnSegment *> one {this};
+	CompactMany(db, one);
+}
+
+void ColumnSegment::CompactMany(DatabaseInstance &db, const std::vector<ColumnSegment *> &segments) {
+	// Batched ColumnSegment::Compact (column_segment.cpp:273-322): per (type, rule) group one upload, one
+	// adac_analyze, the width decision on the host from the downloaded min/max, one adac_pack.
+	std::map<std::pair<uint8_t, int>, std::vector<ColumnSegment *>> groups;
+	for (auto *s : segments) {
+		if (!s->NeedsCompaction()) continue;
+		int rule = s->function->type == CompressionType::COMPRESSION_SUCCINCT ? ADAC_RULE_APPEND : ADAC_RULE_RECOMPACT;
+		groups[{(uint8_t)s->type, rule}].push_back(s);
+	}
+	const bool padded = db.config.succinct_padded_to_next_byte_enabled;
+	for (auto &g : groups) {
+		const int ptype = g.first.first;
+		const int rule = g.first.second;
+		auto &segs = g.second;
+		const idx_t ts = adac_type_size(ptype);
+		const idx_t per16 = 16 / ts;
+		std::vector<uint32_t> counts(segs.size());
+		std::vector<uint64_t> offs(segs.size());
+		uint64_t span = 0;
+		bool any_null = false;
+		for (size_t i = 0; i < segs.size(); i++) {
+			counts[i] = (uint32_t)segs[i]->count;
+			offs[i] = span;
+			span += (segs[i]->count + per16 - 1) / per16 * per16; // keep every segment 16-byte aligned
+			any_null |= (rule == ADAC_RULE_APPEND && segs[i]->any_null);
+		}
+		std::vector<uint8_t> host(span * ts + 16, 0);
+		std::vector<uint64_t> vmask;
+		if (any_null) vmask.assign(span / 64 + 2, ~0ull);
+		for (size_t i = 0; i < segs.size(); i++) {
+			std::memcpy(host.data() + offs[i] * ts, segs[i]->raw.data(), segs[i]->count * ts);
+			if (any_null && segs[i]->any_null) {
+				for (idx_t r = 0; r < segs[i]->count; r++) {
+					if (!((segs[i]->validity[r >> 6] >> (r & 63)) & 1)) {
+						uint64_t e = offs[i] + r;
+						vmask[e >> 6] &= ~(1ull << (e & 63));
+					}
+				}
+			}
+		}
+		std::vector<uint64_t> mm(2 * segs.size());
+		std::vector<adac_segment_desc> descs;
+		std::vector<size_t> pidx;
+		std::vector<uint8_t> widths(segs.size());
+		std::shared_ptr<LayoutHandle> handle;
+		{ // device work under the pool lock; representation flips (bit_compression_lock) after it is released
+		std::lock_guard<std::mutex> pg(db.pool.lock);
+		adac_ctx *ctx = db.pool.ctx;
+		void *d_vals = db.pool.Staging(host.size());
+		Check(adac_memcpy_h2d(ctx, d_vals, host.data(), host.size()), "upload rows");
+		uint64_t *d_valid = nullptr;
+		if (any_null) {
+			d_valid = static_cast<uint64_t *>(db.pool.Staging2(vmask.size() * 8));
+			Check(adac_memcpy_h2d(ctx, d_valid, vmask.data(), vmask.size() * 8), "upload validity");
+		}
+		adac_layout *probe = nullptr;
+		Check(adac_layout_create(ctx, ptype, counts.data(), offs.data(), segs.size(), &probe), "adac_layout_create");
+		adac_status st = adac_analyze(probe, d_vals, d_valid, rule);
+		if (st == ADAC_OK) st = adac_layout_get_minmax(probe, mm.data());
+		adac_layout_destroy(probe);
+		Check(st, "adac_analyze");
+		// width decision (column_segment.cpp:351-363 / :404-420) and arena placement
+		std::vector<uint32_t> pcounts;
+		std::vector<uint64_t> poffs;
+		for (size_t i = 0; i < segs.size(); i++) {
+			uint8_t w = adac_width(mm[2 * i], mm[2 * i + 1], rule, padded);
+			widths[i] = w;
+			if (8 * ts > w) {
+				adac_segment_desc d;
+				d.word_off = db.pool.Allocate(adac_arena_words(counts[i], w));
+				d.val_off = offs[i];
+				d.min = mm[2 * i];
+				d.count = counts[i];
+				d.width = w;
+				d.flags = ADAC_SEG_PACKED;
+				d.reserved = 0;
+				descs.push_back(d);
+				pcounts.push_back(counts[i]);
+				poffs.push_back(offs[i]);
+				pidx.push_back(i);
+			}
+		}
+		if (!descs.empty()) {
+			handle = std::make_shared<LayoutHandle>();
+			Check(adac_layout_create(ctx, ptype, pcounts.data(), poffs.data(), descs.size(), &handle->layout),
+			      "adac_layout_create");
+			Check(adac_layout_set_descs(handle->layout, descs.data()), "adac_layout_set_descs");
+			Check(adac_pack(handle->layout, d_vals, d_valid, db.pool.d_arena), "adac_pack");
+			Check(adac_ctx_sync(ctx), "adac_ctx_sync");
+		}
+		} // pool lock released
+		size_t p = 0;
+		for (size_t i = 0; i < segs.size(); i++) {
+			bool packed = p < pidx.size() && pidx[p] == i;
+			if (packed) SetRef(segs[i], SegmentDeviceRef {handle, p});
+			segs[i]->FinishCompaction(packed, widths[i], mm[2 * i], mm[2 * i + 1], rule,
+			                          packed ? descs[p].word_off : 0);
+			if (packed) p++;
+		}
+	}
+}
+
+void ColumnSegment::FinishCompaction(bool packed, uint8_t width, uint64_t mn, uint64_t mx, int rule, uint64_t off) {
+	std::lock_guard<std::mutex> g(bit_compression_lock);
+	const idx_t before = GetDataSize();
+	if (rule == ADAC_RULE_APPEND) {
+		// what UpdateMinFactor/UpdateMaxFactor accumulated during the appends (succinct.cpp:317-318)
+		min_factor = std::min(min_factor, mn);
+		max_factor = std::max(max_factor, mx);
+	} else {
+		// succinct_vec.width(8*type_size); resize(segment_size / type_size)  (column_segment.cpp:304-305)
+		vec_width = (uint8_t)(8 * type_size);
+		vec_slots = segment_size / type_size;
+		// the product stores the frame of reference of the recompaction (reference defect 2)
+		min_factor = packed ? mn : UINT64_MAX;
+	}
+	if (packed) {
+		vec_slots = count; // bit_resize(count * w)
+		vec_width = width;
+		packed_on_device = true;
+		word_off = off;
+		arena_words = adac_arena_words(count, width);
+		std::vector<uint8_t>().swap(raw); // the unpacked image is gone, as after SDSL's realloc shrink
+	}
+	std::vector<uint64_t>().swap(validity);
+	any_null = false;
+	function = db.GetCompressionFunction(CompressionType::COMPRESSION_SUCCINCT, type);
+	compacted = true;
+	db.data_size += (int64_t)GetDataSize() - (int64_t)before;
+}
+
+void ColumnSegment::Uncompact() {
+	// column_segment.cpp:324-346 + UncompressSuccinct :458-506
+	if (!compacted || !function || function->type != CompressionType::COMPRESSION_SUCCINCT) return;
+	std::lock_guard<std::mutex> g(bit_compression_lock);
+	const idx_t compressed_size = adac_size_in_bytes(vec_slots, vec_width);
+	if (packed_on_device) {
+		raw.assign(segment_size, 0);
+		SegmentDeviceRef ref = GetRef(this);
+		std::lock_guard<std::mutex> pg(db.pool.lock);
+		if (count) {
+			void *d_out = db.pool.Staging(count * type_size);
+			Check(adac_unpack_range(ref.layout->layout, db.pool.d_arena, ref.index, 0, count, d_out, 0),
+			      "adac_unpack_range");
+			Check(adac_memcpy_d2h(db.pool.ctx, raw.data(), d_out, count * type_size), "adac_memcpy_d2h");
+		}
+		db.pool.Free(word_off, arena_words);
+		packed_on_device = false;
+		DropRef(this);
+	}
+	function = db.GetCompressionFunction(CompressionType::COMPRESSION_UNCOMPRESSED, type);
+	compacted = false;
+	vec_slots = 0; // succinct_vec.resize(0)
+	force_reinitializing_scan_state = true;
+	db.data_size += (int64_t)segment_size - (int64_t)compressed_size;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ColumnSegmentCatalog
+// ------------------------------------------------------------------------------------------------
+
+ColumnSegmentCatalog::ColumnSegmentCatalog(DatabaseInstance &db_p) : db(db_p) {
+}
+
+ColumnSegmentCatalog::~ColumnSegmentCatalog() {
+	DisableBackgroundThreadCompaction();
+}
+
+void ColumnSegmentCatalog::AddColumnSegment(ColumnSegment *segment) {
+	if (!segment->is_data_segment) return;
+	std::lock_guard<std::mutex> g(lock);
+	statistics[segment] = AccessStatistics {0};
+}
+
+void ColumnSegmentCatalog::RemoveColumnSegment(ColumnSegment *segment) {
+	std::lock_guard<std::mutex> g(lock);
+	statistics.erase(segment);
+}
+
+void ColumnSegmentCatalog::AddReadAccess(ColumnSegment *segment) {
+	// column_segment_catalog.cpp:37-54
+	if (segment == nullptr || !segment->is_data_segment) return;
+	std::lock_guard<std::mutex> g(lock);
+	auto it = statistics.find(segment);
+	if (it == statistics.end()) {
+		statistics[segment] = AccessStatistics {1};
+	} else {
+		it->second.num_reads++;
+		event_counter++;
+	}
+}
+
+idx_t ColumnSegmentCatalog::NumSegments() {
+	std::lock_guard<std::mutex> g(lock);
+	return statistics.size();
+}
+
+void ColumnSegmentCatalog::CompactAllSegments() {
+	std::vector<ColumnSegment *> all;
+	{
+		std::lock_guard<std::mutex> g(lock);
+		for (auto &e : statistics) all.push_back(e.first);
+	}
+	ColumnSegment::CompactMany(db, all);
+}
+
+size_t ColumnSegmentCatalog::GetTotalDataSize() {
+	std::lock_guard<std::mutex> g(lock);
+	size_t data_size = 0;
+	for (auto &e : statistics) data_size += e.first->GetDataSize();
+	return data_size;
+}
+
+void ColumnSegmentCatalog::CompressLowestKSegmentsOnce(double compression_rate) {
+	// column_segment_catalog.cpp:79-112.  The reference sorts by num_reads only (ties in unordered_map
+	// order); ties are broken here by the segment's start row, then address, to be deterministic.
+	std::vector<std::pair<ColumnSegment *, AccessStatistics>> v;
+	{
+		std::lock_guard<std::mutex> g(lock);
+		v.assign(statistics.begin(), statistics.end());
+	}
+	std::sort(v.begin(), v.end(), [](const std::pair<ColumnSegment *, AccessStatistics> &l,
+	                                 const std::pair<ColumnSegment *, AccessStatistics> &r) {
+		if (l.second.num_reads != r.second.num_reads) return l.second.num_reads < r.second.num_reads;
+		if (l.first->start != r.first->start) return l.first->start < r.first->start;
+		return l.first < r.first;
+	});
+	std::vector<ColumnSegment *> to_compact, to_uncompact;
+	float cum_sum = 0;
+	idx_t curr_counter = v.size();
+	for (auto &e : v) {
+		cum_sum += 1;
+		if (cum_sum / curr_counter < compression_rate) {
+			to_compact.push_back(e.first);
+		} else {
+			to_uncompact.push_back(e.first);
+		}
+	}
+	ColumnSegment::CompactMany(db, to_compact);
+	for (auto *s : to_uncompact) s->Uncompact();
+	{
+		std::lock_guard<std::mutex> g(lock);
+		for (auto &e : v) {
+			auto it = statistics.find(e.first);
+			if (it != statistics.end()) it->second.num_reads = 0;
+		}
+	}
+	event_counter = 0;
+}
+
+void ColumnSegmentCatalog::EnableBackgroundThreadCompaction(unsigned period_ms) {
+	// column_segment_catalog.cpp:13-22 (the reference detaches the thread and sleeps 10 s per round)
+	if (background_compaction_enabled.exchange(true)) return;
+	stop = false;
+	worker = std::thread([this, period_ms]() {
+		while (!stop) {
+			for (unsigned waited = 0; waited < period_ms && !stop; waited += 5) {
+				std::this_thread::sleep_for(std::chrono::milliseconds(5));
+			}
+			if (stop) break;
+			CompressLowestKSegmentsOnce(0.90);
+		}
+	});
+}
+
+void ColumnSegmentCatalog::DisableBackgroundThreadCompaction() {
+	stop = true;
+	if (worker.joinable()) worker.join();
+	background_compaction_enabled = false;
+}
+
+} // namespace adacodec
+
+// ------------------------------------------------------------------------------------------------
+// C wrappers (include/adacodec_host.h): let non-C++ hosts and the Python tests drive the mirror.
+// ------------------------------------------------------------------------------------------------
+
+using namespace adacodec;
+
+struct adach_db {
+	std::unique_ptr<DatabaseInstance> db;
+};
+struct adach_segment {
+	std::unique_ptr<ColumnSegment> seg;
+};
+
+static thread_local std::string g_host_error;
+
+template <typename F>
+static int Guard(F &&f) {
+	try {
+		f();
+		return 0;
+	} catch (const std::exception &e) {
+		g_host_error = e.what();
+		return 1;
+	}
+}
+
+extern "C" const char *adach_last_error(void) {
+	return g_host_error.c_str();
+}
+
+extern "C" adach_db *adach_db_create(int device, int succinct_enabled, int adaptive, int padded, uint64_t arena_bytes) {
+	adach_db *h = nullptr;
+	Guard([&]() {
+		DBConfig cfg;
+		cfg.succinct_enabled = succinct_enabled != 0;
+		cfg.adaptive_succinct_compression_enabled = adaptive != 0;
+		cfg.succinct_padded_to_next_byte_enabled = padded != 0;
+		auto db = std::unique_ptr<DatabaseInstance>(new DatabaseInstance(device, cfg, arena_bytes));
+		h = new adach_db {std::move(db)};
+	});
+	return h;
+}
+
+extern "C" void adach_db_destroy(adach_db *h) {
+	delete h;
+}
+
+extern "C" adach_segment *adach_segment_create(adach_db *h, int physical_type, uint64_t start, uint64_t segment_size) {
+	adach_segment *s = nullptr;
+	Guard([&]() {
+		if (!adac_type_is_supported(physical_type)) throw InternalException("Unsupported type for the succinct codec");
+		auto seg = ColumnSegment::CreateTransientSegment(*h->db, (PhysicalType)physical_type, start, segment_size);
+		s = new adach_segment {std::move(seg)};
+	});
+	return s;
+}
+
+extern "C" void adach_segment_destroy(adach_segment *s) {
+	delete s;
+}
+
+extern "C" int64_t adach_segment_append(adach_segment *s, const void *vals, const uint64_t *validity, const uint32_t *sel,
+                                        uint64_t offset, uint64_t count) {
+	int64_t copied = -1;
+	Guard([&]() {
+		UnifiedVectorFormat f;
+		f.data = static_cast<const uint8_t *>(vals);
+		f.validity = validity;
+		f.sel = sel;
+		copied = (int64_t)s->seg->Append(f, offset, count);
+	});
+	return copied;
+}
+
+extern "C" int adach_segment_scan(adach_segment *s, uint64_t row_index, uint64_t count, void *result,
+                                  uint64_t result_offset, int entire_vector) {
+	return Guard([&]() {
+		ColumnScanState st;
+		st.row_index = row_index;
+		Vector v;
+		v.data = static_cast<data_ptr_t>(result);
+		s->seg->Scan(st, count, v, result_offset, entire_vector != 0);
+	});
+}
+
+extern "C" int adach_segment_fetch_row(adach_segment *s, int64_t row_id, void *result, uint64_t result_idx) {
+	return Guard([&]() {
+		ColumnFetchState st;
+		Vector v;
+		v.data = static_cast<data_ptr_t>(result);
+		s->seg->FetchRow(st, row_id, v, result_idx);
+	});
+}
+
+extern "C" int adach_segment_compact(adach_segment *s) {
+	return Guard([&]() { s->seg->Compact(); });
+}
+extern "C" int adach_segment_uncompact(adach_segment *s) {
+	return Guard([&]() { s->seg->Uncompact(); });
+}
+extern "C" uint64_t adach_segment_count(adach_segment *s) {
+	return s->seg->count;
+}
+extern "C" uint64_t adach_segment_min(adach_segment *s) {
+	return s->seg->GetMinFactor();
+}
+extern "C" uint64_t adach_segment_max(adach_segment *s) {
+	return s->seg->GetMax();
+}
+extern "C" uint32_t adach_segment_width(adach_segment *s) {
+	return s->seg->Width();
+}
+extern "C" int adach_segment_compacted(adach_segment *s) {
+	return s->seg->IsBitCompressed();
+}
+extern "C" int adach_segment_function(adach_segment *s) {
+	return (int)s->seg->function->type;
+}
+extern "C" uint64_t adach_segment_data_size(adach_segment *s) {
+	return s->seg->GetDataSize();
+}
+
+extern "C" int adach_catalog_compact_all(adach_db *h) {
+	return Guard([&]() { h->db->catalog.CompactAllSegments(); });
+}
+extern "C" uint64_t adach_catalog_total_data_size(adach_db *h) {
+	return h->db->catalog.GetTotalDataSize();
+}
+extern "C" uint64_t adach_catalog_num_segments(adach_db *h) {
+	return h->db->catalog.NumSegments();
+}
+extern "C" int adach_catalog_policy_step(adach_db *h, double compression_rate) {
+	return Guard([&]() { h->db->catalog.CompressLowestKSegmentsOnce(compression_rate); });
+}
+extern "C" int adach_catalog_enable_background(adach_db *h, unsigned period_ms) {
+	return Guard([&]() { h->db->catalog.EnableBackgroundThreadCompaction(period_ms); });
+}
+extern "C" int adach_catalog_disable_background(adach_db *h) {
+	return Guard([&]() { h->db->catalog.DisableBackgroundThreadCompaction(); });
+}
+extern "C" int64_t adach_db_data_size(adach_db *h) {
+	return h->db->data_size.load();
+}
+extern "C" uint64_t adach_db_arena_used_bytes(adach_db *h) {
+	return h->db->pool.UsedWords() * 8;
+}
+extern "C" int adach_type_is_supported(int physical_type) {
+	return SuccinctFun::TypeIsSupported((PhysicalType)physical_type) ? 1 : 0;
+}

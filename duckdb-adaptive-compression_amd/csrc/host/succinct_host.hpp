@@ -1,0 +1,263 @@
+// succinct_host.hpp — host-side mirror of the reference's succinct plumbing, in the reference's own language
+// (C++) and with its names, built ONLY on the C ABI of include/adacodec.h (device work) and memcpy (host work:
+// no value arithmetic happens on the CPU).  It is what the DuckDB adapter of INTEGRATION.md would be made of,
+// kept self-contained (no DuckDB headers) so it builds and is tested on its own.
+//
+// Mirrors (paths relative to the reference checkout):
+//   DBConfig flags                      src/include/duckdb/main/config.hpp:189-197
+//   CompressionFunction (slot table)    src/include/duckdb/function/compression_function.hpp:65-177
+//   SuccinctFun::GetFunction/TypeIs...  src/storage/compression/succinct.cpp:335-382
+//   ColumnSegment succinct state        src/include/duckdb/storage/table/column_segment.hpp:60-64,139-214
+//     CreateTransientSegment / ctor     src/storage/table/column_segment.cpp:45-110
+//     Scan / ScanPartial / FetchRow     src/storage/table/column_segment.cpp:137-196
+//     Append / Compact / Uncompact      src/storage/table/column_segment.cpp:247-346
+//     GetDataSize / SuccinctSize        src/storage/table/column_segment.cpp:204-222
+//   ColumnSegmentCatalog                src/catalog/catalog_entry/column_segment_catalog.cpp:24-135
+#pragma once
+
+#include <atomic>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "adacodec.h"
+
+namespace adacodec {
+
+using idx_t = uint64_t;
+using row_t = int64_t;
+using data_ptr_t = uint8_t *;
+
+constexpr idx_t STANDARD_VECTOR_SIZE = 2048; // src/include/duckdb/common/vector_size.hpp:17
+constexpr idx_t BLOCK_SIZE = 262144 - 8;     // Storage::BLOCK_SIZE, src/include/duckdb/common/constants.hpp:104-106
+
+// duckdb::PhysicalType codes of the supported types (src/include/duckdb/common/types.hpp:117-138)
+enum class PhysicalType : uint8_t { UINT8 = 2, INT8 = 3, UINT16 = 4, INT16 = 5, UINT32 = 6, INT32 = 7, UINT64 = 8, INT64 = 9 };
+
+// src/include/duckdb/common/enums/compression_type.hpp:17-27
+enum class CompressionType : uint8_t { COMPRESSION_UNCOMPRESSED = 1, COMPRESSION_SUCCINCT = 10 };
+
+class InternalException : public std::runtime_error {
+public:
+	explicit InternalException(const std::string &msg) : std::runtime_error(msg) {
+	}
+};
+
+// The four public booleans of DBConfig (config.hpp:189-197).
+struct DBConfig {
+	bool succinct_enabled = true;
+	bool succinct_extract_prefix_enabled = true; // read only by the reference's dead SuccinctScanAndCompact
+	bool succinct_padded_to_next_byte_enabled = false;
+	bool adaptive_succinct_compression_enabled = false;
+};
+
+// The slice of duckdb::UnifiedVectorFormat the append slot reads (data, selection vector, validity mask).
+struct UnifiedVectorFormat {
+	const uint8_t *data = nullptr;
+	const uint32_t *sel = nullptr;      // nullptr = identity
+	const uint64_t *validity = nullptr; // nullptr = all valid; bit i of word i/64 set = row i valid
+};
+
+// The slice of duckdb::Vector a scan writes: flat data of the segment's type.
+struct Vector {
+	data_ptr_t data = nullptr;
+	bool flat = true;
+};
+
+struct ColumnScanState {
+	idx_t row_index = 0; // absolute row; the segment subtracts its start
+};
+struct ColumnFetchState {};
+
+class ColumnSegment;
+class ColumnSegmentCatalog;
+class DatabaseInstance;
+
+// The function-pointer table (compression_function.hpp:105-177), scan/append half: the checkpoint-side slots
+// (init_analyze .. compress_finalize) do not exist for an in-memory codec (succinct.cpp:91-119 prints
+// "SHOULD NOT HAPPEN").
+struct CompressionFunction {
+	CompressionType type;
+	PhysicalType data_type;
+	void (*scan_vector)(ColumnSegment &segment, ColumnScanState &state, idx_t scan_count, Vector &result);
+	void (*scan_partial)(ColumnSegment &segment, ColumnScanState &state, idx_t scan_count, Vector &result,
+	                     idx_t result_offset);
+	void (*fetch_row)(ColumnSegment &segment, ColumnFetchState &state, row_t row_id, Vector &result, idx_t result_idx);
+	void (*skip)(ColumnSegment &segment, ColumnScanState &state, idx_t skip_count);
+	idx_t (*append)(ColumnSegment &segment, UnifiedVectorFormat &data, idx_t offset, idx_t count);
+	idx_t (*finalize_append)(ColumnSegment &segment);
+};
+
+struct SuccinctFun {
+	static CompressionFunction GetFunction(PhysicalType data_type); // throws InternalException if unsupported
+	static bool TypeIsSupported(PhysicalType type);
+};
+struct UncompressedFun {
+	static CompressionFunction GetFunction(PhysicalType data_type);
+};
+
+// One GPU's segment pool: context, packed arena (first-fit over 128-byte units) and staging buffers.
+class SegmentPool {
+public:
+	SegmentPool(int device, size_t arena_bytes);
+	~SegmentPool();
+	adac_ctx *ctx = nullptr;
+	uint64_t *d_arena = nullptr;
+	uint64_t arena_words = 0;
+
+	uint64_t Allocate(uint64_t words); // returns word offset (multiple of 16); throws when exhausted
+	void Free(uint64_t word_off, uint64_t words);
+	uint64_t UsedWords() const {
+		return used_words;
+	}
+	void *Staging(size_t bytes);   // device scratch, grown on demand
+	void *Staging2(size_t bytes);  // second device scratch (validity)
+	std::mutex lock;               // serialises device work of this pool (one stream)
+
+private:
+	std::map<uint64_t, uint64_t> free_list; // offset -> length
+	uint64_t used_words = 0;
+	void *d_staging = nullptr;
+	size_t staging_bytes = 0;
+	void *d_staging2 = nullptr;
+	size_t staging2_bytes = 0;
+};
+
+struct AccessStatistics {
+	idx_t num_reads = 0;
+};
+
+// column_segment_catalog.hpp:23-49
+class ColumnSegmentCatalog {
+public:
+	explicit ColumnSegmentCatalog(DatabaseInstance &db);
+	~ColumnSegmentCatalog();
+	void AddColumnSegment(ColumnSegment *segment);
+	void AddReadAccess(ColumnSegment *segment);
+	void RemoveColumnSegment(ColumnSegment *segment);
+	void CompactAllSegments();
+	size_t GetTotalDataSize();
+	// One iteration of CompressLowestKSegments (column_segment_catalog.cpp:64-116) without the sleep: sort by
+	// num_reads, Compact the first `compression_rate` share, Uncompact the rest, reset the counters.
+	void CompressLowestKSegmentsOnce(double compression_rate = 0.90);
+	void EnableBackgroundThreadCompaction(unsigned period_ms = 10000);
+	void DisableBackgroundThreadCompaction();
+	bool BackgroundCompactionEnabled() const {
+		return background_compaction_enabled;
+	}
+	idx_t NumSegments();
+	idx_t EventCounter() const {
+		return event_counter;
+	}
+
+private:
+	DatabaseInstance &db;
+	std::mutex lock; // the reference mutates the map unlocked (TSan suppression `race:~ColumnSegment`)
+	std::unordered_map<ColumnSegment *, AccessStatistics> statistics;
+	std::atomic<idx_t> event_counter {0};
+	std::atomic<bool> background_compaction_enabled {false};
+	std::atomic<bool> stop {false};
+	std::thread worker;
+};
+
+class DatabaseInstance {
+public:
+	DatabaseInstance(int device, const DBConfig &config, size_t arena_bytes);
+	DBConfig config;
+	SegmentPool pool;
+	ColumnSegmentCatalog catalog;
+	std::atomic<int64_t> data_size {0}; // BufferManager::data_size accounting (buffer_manager.hpp:71-82)
+	const CompressionFunction *GetCompressionFunction(CompressionType type, PhysicalType data_type);
+
+private:
+	std::mutex fn_lock;
+	std::map<std::pair<uint8_t, uint8_t>, CompressionFunction> functions; // lazy registry, compression_config.cpp:85-94
+};
+
+class ColumnSegment {
+public:
+	static std::unique_ptr<ColumnSegment> CreateTransientSegment(DatabaseInstance &db, PhysicalType type, idx_t start,
+	                                                             idx_t segment_size = BLOCK_SIZE);
+	~ColumnSegment();
+
+	DatabaseInstance &db;
+	PhysicalType type;
+	idx_t type_size;
+	idx_t start;
+	idx_t count = 0; // SegmentBase::count
+	const CompressionFunction *function;
+	bool succinct_possible;
+	bool is_data_segment = true;
+
+	void Scan(ColumnScanState &state, idx_t scan_count, Vector &result, idx_t result_offset, bool entire_vector);
+	void FetchRow(ColumnFetchState &state, row_t row_id, Vector &result, idx_t result_idx);
+	void Skip(ColumnScanState &state);
+	idx_t SegmentSize() const {
+		return segment_size;
+	}
+	idx_t GetDataSize() const;
+	idx_t SuccinctSize() const;
+	idx_t Append(UnifiedVectorFormat &data, idx_t offset, idx_t count);
+	idx_t FinalizeAppend();
+	idx_t GetRelativeIndex(idx_t row_index) const {
+		return row_index - start;
+	}
+	uint64_t GetMinFactor() const {
+		return min_factor;
+	}
+	uint64_t GetMax() const {
+		return max_factor;
+	}
+	bool IsBitCompressed() const {
+		return compacted;
+	}
+	void Compact();
+	void Uncompact();
+	uint8_t Width() const {
+		return vec_width;
+	}
+	idx_t NumElements() const {
+		return num_elements;
+	}
+
+	// batched forms used by the catalog: one upload, one analyze, one pack for many segments
+	static void CompactMany(DatabaseInstance &db, const std::vector<ColumnSegment *> &segments);
+
+	// codec internals reached by the CompressionFunction callbacks
+	void ScanRows(idx_t start_row, idx_t scan_count, data_ptr_t target);
+	idx_t AppendRows(UnifiedVectorFormat &data, idx_t offset, idx_t count);
+
+	ColumnSegment(DatabaseInstance &db, PhysicalType type, idx_t start, idx_t segment_size, const CompressionFunction *fn,
+	              bool succinct_possible, bool background_compaction_enabled);
+
+private:
+	friend class ColumnSegmentCatalog;
+	bool NeedsCompaction() const;
+	void FinishCompaction(bool packed, uint8_t width, uint64_t mn, uint64_t mx, int rule, uint64_t word_off);
+
+	idx_t num_elements = 0;
+	idx_t segment_size;
+	uint64_t min_factor = UINT64_MAX;
+	uint64_t max_factor = 0;
+	bool compacted = false;
+	bool background_compaction_enabled;
+	bool force_reinitializing_scan_state = false;
+	std::mutex bit_compression_lock;
+
+	// succinct_vec, as {slots, width}; its bits live in `raw` (unpacked) or in the pool arena (packed)
+	idx_t vec_slots = 0;
+	uint8_t vec_width = 64;
+	bool packed_on_device = false;
+	uint64_t word_off = 0, arena_words = 0;
+	std::vector<uint8_t> raw;          // slots at 8*sizeof(T) bits / the uncompressed block
+	std::vector<uint64_t> validity;    // NULL rows of the append phase (consumed by the first compaction)
+	bool any_null = false;
+	bool appended_via_succinct = false; // true: min/max follow the append rule; false: the recompaction rule
+};
+
+} // namespace adacodec

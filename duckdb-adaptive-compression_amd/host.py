@@ -1,0 +1,171 @@
+"""ctypes binding of include/adacodec_host.h — the C wrappers of the C++ host mirror (csrc/host/):
+the reference's ColumnSegment / CompressionFunction / ColumnSegmentCatalog state machine on one GPU pool."""
+import ctypes as C
+
+import numpy as np
+
+from . import AdacError, lib as _codec_lib, physical_type, LIB_PATH  # noqa: F401
+
+FN_UNCOMPRESSED, FN_SUCCINCT = 1, 10
+_u64, _i64, _u32, _int, _vp = C.c_uint64, C.c_int64, C.c_uint32, C.c_int, C.c_void_p
+
+HOST_SIGNATURES = {
+    "adach_last_error": (C.c_char_p, []),
+    "adach_type_is_supported": (_int, [_int]),
+    "adach_db_create": (_vp, [_int, _int, _int, _int, _u64]),
+    "adach_db_destroy": (None, [_vp]),
+    "adach_db_data_size": (_i64, [_vp]),
+    "adach_db_arena_used_bytes": (_u64, [_vp]),
+    "adach_segment_create": (_vp, [_vp, _int, _u64, _u64]),
+    "adach_segment_destroy": (None, [_vp]),
+    "adach_segment_append": (_i64, [_vp, _vp, _vp, _vp, _u64, _u64]),
+    "adach_segment_scan": (_int, [_vp, _u64, _u64, _vp, _u64, _int]),
+    "adach_segment_fetch_row": (_int, [_vp, _i64, _vp, _u64]),
+    "adach_segment_compact": (_int, [_vp]),
+    "adach_segment_uncompact": (_int, [_vp]),
+    "adach_segment_count": (_u64, [_vp]),
+    "adach_segment_min": (_u64, [_vp]),
+    "adach_segment_max": (_u64, [_vp]),
+    "adach_segment_width": (_u32, [_vp]),
+    "adach_segment_compacted": (_int, [_vp]),
+    "adach_segment_function": (_int, [_vp]),
+    "adach_segment_data_size": (_u64, [_vp]),
+    "adach_catalog_compact_all": (_int, [_vp]),
+    "adach_catalog_total_data_size": (_u64, [_vp]),
+    "adach_catalog_num_segments": (_u64, [_vp]),
+    "adach_catalog_policy_step": (_int, [_vp, C.c_double]),
+    "adach_catalog_enable_background": (_int, [_vp, C.c_uint]),
+    "adach_catalog_disable_background": (_int, [_vp]),
+}
+
+_ready = False
+
+
+def hlib():
+    global _ready
+    L = _codec_lib()
+    if not _ready:
+        for name, (res, args) in HOST_SIGNATURES.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _ready = True
+    return L
+
+
+class HostError(RuntimeError):
+    pass
+
+
+def _ok(rc, where):
+    if rc != 0:
+        raise HostError("%s: %s" % (where, hlib().adach_last_error().decode()))
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Database:
+    """DBConfig flags + one GPU segment pool + the ColumnSegmentCatalog."""
+
+    def __init__(self, device=0, succinct_enabled=True, adaptive=False, padded=False, arena_bytes=1 << 30):
+        self._h = hlib().adach_db_create(device, int(succinct_enabled), int(adaptive), int(padded), arena_bytes)
+        if not self._h:
+            raise HostError("adach_db_create: %s" % hlib().adach_last_error().decode())
+        self.segments = []
+
+    def close(self):
+        if self._h:
+            hlib().adach_catalog_disable_background(self._h)
+        for s in self.segments:
+            s.close()
+        self.segments = []
+        if self._h:
+            hlib().adach_db_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pragma: no cover
+            pass
+
+    def create_segment(self, dtype, start=0, segment_size=262136):
+        s = Segment(self, dtype, start, segment_size)
+        self.segments.append(s)
+        return s
+
+    def compact_all(self):
+        _ok(hlib().adach_catalog_compact_all(self._h), "CompactAllSegments")
+
+    def policy_step(self, rate=0.90):
+        _ok(hlib().adach_catalog_policy_step(self._h, rate), "CompressLowestKSegments")
+
+    def enable_background(self, period_ms):
+        _ok(hlib().adach_catalog_enable_background(self._h, period_ms), "EnableBackgroundThreadCompaction")
+
+    def disable_background(self):
+        _ok(hlib().adach_catalog_disable_background(self._h), "DisableBackgroundThreadCompaction")
+
+    total_data_size = property(lambda s: hlib().adach_catalog_total_data_size(s._h))
+    num_segments = property(lambda s: hlib().adach_catalog_num_segments(s._h))
+    data_size = property(lambda s: hlib().adach_db_data_size(s._h))
+    arena_used_bytes = property(lambda s: hlib().adach_db_arena_used_bytes(s._h))
+
+
+class Segment:
+    def __init__(self, db, dtype, start, segment_size):
+        self.db = db
+        self.dtype = np.dtype(dtype)
+        self.start = start
+        self._h = hlib().adach_segment_create(db._h, physical_type(dtype), start, segment_size)
+        if not self._h:
+            raise HostError("adach_segment_create: %s" % hlib().adach_last_error().decode())
+
+    def close(self):
+        if self._h:
+            hlib().adach_segment_destroy(self._h)
+            self._h = None
+
+    def append(self, vals, validity=None, sel=None, offset=0, count=None):
+        vals = np.ascontiguousarray(vals, dtype=self.dtype)
+        if count is None:
+            count = (len(vals) if sel is None else len(sel)) - offset
+        if validity is not None:
+            validity = np.ascontiguousarray(validity, dtype=np.uint64)
+        if sel is not None:
+            sel = np.ascontiguousarray(sel, dtype=np.uint32)
+        n = hlib().adach_segment_append(self._h, _p(vals), _p(validity), _p(sel), offset, count)
+        if n < 0:
+            raise HostError("Append: %s" % hlib().adach_last_error().decode())
+        return n
+
+    def scan(self, row, count, result=None, result_offset=0, entire_vector=None):
+        """row: segment-relative row. Returns the rows scanned."""
+        if entire_vector is None:
+            entire_vector = result_offset == 0
+        if result is None:
+            result = np.empty(result_offset + count, dtype=self.dtype)
+        _ok(hlib().adach_segment_scan(self._h, self.start + row, count, _p(result), result_offset, int(entire_vector)),
+            "Scan")
+        return result[result_offset:result_offset + count]
+
+    def fetch_row(self, row):
+        out = np.empty(1, dtype=self.dtype)
+        _ok(hlib().adach_segment_fetch_row(self._h, self.start + row, _p(out), 0), "FetchRow")
+        return out[0]
+
+    def compact(self):
+        _ok(hlib().adach_segment_compact(self._h), "Compact")
+
+    def uncompact(self):
+        _ok(hlib().adach_segment_uncompact(self._h), "Uncompact")
+
+    count = property(lambda s: hlib().adach_segment_count(s._h))
+    min_factor = property(lambda s: hlib().adach_segment_min(s._h))
+    max_factor = property(lambda s: hlib().adach_segment_max(s._h))
+    width = property(lambda s: hlib().adach_segment_width(s._h))
+    compacted = property(lambda s: bool(hlib().adach_segment_compacted(s._h)))
+    function = property(lambda s: hlib().adach_segment_function(s._h))
+    data_size = property(lambda s: hlib().adach_segment_data_size(s._h))

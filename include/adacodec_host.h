@@ -1,0 +1,68 @@
+/*
+ * adacodec_host.h — C wrappers around the C++ host mirror (csrc/host/succinct_host.hpp) of the reference's
+ * ColumnSegment / CompressionFunction / ColumnSegmentCatalog plumbing.  They exist so hosts without a C++
+ * toolchain — and the Python tests — can drive the same state machine the DuckDB adapter would
+ * (INTEGRATION.md).  All value arithmetic happens on the device through include/adacodec.h; functions
+ * returning int return 0 on success and 1 on failure (text in adach_last_error()).
+ *
+ * Reference interfaces mirrored (paths relative to the reference checkout):
+ *   adach_db_create               DBConfig flags (src/include/duckdb/main/config.hpp:189-197) + one GPU segment pool
+ *   adach_segment_create          ColumnSegment::CreateTransientSegment (src/storage/table/column_segment.cpp:45-82)
+ *   adach_segment_append          ColumnSegment::Append (column_segment.cpp:247-271) -> append slot (succinct.cpp:308-322)
+ *   adach_segment_scan            ColumnSegment::Scan / ScanPartial (column_segment.cpp:137-188) -> scan_vector / scan_partial
+ *   adach_segment_fetch_row       ColumnSegment::FetchRow (column_segment.cpp:193-195) -> fetch_row slot
+ *   adach_segment_compact/uncompact   ColumnSegment::Compact / Uncompact (column_segment.cpp:273-346)
+ *   adach_segment_data_size       ColumnSegment::GetDataSize (column_segment.cpp:204-214)
+ *   adach_catalog_*               ColumnSegmentCatalog (src/catalog/catalog_entry/column_segment_catalog.cpp:24-135)
+ */
+#ifndef ADACODEC_HOST_H
+#define ADACODEC_HOST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct adach_db adach_db;
+typedef struct adach_segment adach_segment;
+
+const char *adach_last_error(void);
+int adach_type_is_supported(int physical_type);
+
+/* arena_bytes: capacity of this GPU's packed-segment arena. NULL on failure (e.g. no device). */
+adach_db *adach_db_create(int device, int succinct_enabled, int adaptive, int padded, uint64_t arena_bytes);
+void adach_db_destroy(adach_db *db);
+int64_t adach_db_data_size(adach_db *db);          /* BufferManager::GetDataSize analogue */
+uint64_t adach_db_arena_used_bytes(adach_db *db);  /* HBM actually held by packed segments */
+
+adach_segment *adach_segment_create(adach_db *db, int physical_type, uint64_t start, uint64_t segment_size);
+void adach_segment_destroy(adach_segment *seg);
+/* returns rows consumed (the caller opens a new segment for the rest), -1 on error */
+int64_t adach_segment_append(adach_segment *seg, const void *vals, const uint64_t *validity, const uint32_t *sel,
+                             uint64_t offset, uint64_t count);
+int adach_segment_scan(adach_segment *seg, uint64_t row_index, uint64_t count, void *result, uint64_t result_offset,
+                       int entire_vector);
+int adach_segment_fetch_row(adach_segment *seg, int64_t row_id, void *result, uint64_t result_idx);
+int adach_segment_compact(adach_segment *seg);
+int adach_segment_uncompact(adach_segment *seg);
+uint64_t adach_segment_count(adach_segment *seg);
+uint64_t adach_segment_min(adach_segment *seg);
+uint64_t adach_segment_max(adach_segment *seg);
+uint32_t adach_segment_width(adach_segment *seg);
+int adach_segment_compacted(adach_segment *seg);
+int adach_segment_function(adach_segment *seg); /* CompressionType: 1 uncompressed, 10 succinct */
+uint64_t adach_segment_data_size(adach_segment *seg);
+
+int adach_catalog_compact_all(adach_db *db);
+uint64_t adach_catalog_total_data_size(adach_db *db);
+uint64_t adach_catalog_num_segments(adach_db *db);
+/* one round of CompressLowestKSegments without the sleep */
+int adach_catalog_policy_step(adach_db *db, double compression_rate);
+int adach_catalog_enable_background(adach_db *db, unsigned period_ms);
+int adach_catalog_disable_background(adach_db *db);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADACODEC_HOST_H */

@@ -26,6 +26,15 @@ def test_every_declared_symbol_is_exported(adac, lib):
         assert hasattr(raw, name), "libadacodec.so does not export %s" % name
     assert declared == set(adac.SIGNATURES), declared ^ set(adac.SIGNATURES)
     assert lib.adac_abi_version() == 1
+    # the C wrappers of the C++ host mirror (include/adacodec_host.h)
+    import importlib
+    host = importlib.import_module(adac.__name__ + ".host")
+    hdr = open(os.path.join(ROOT, "include", "adacodec_host.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    hdeclared = set(re.findall(r"\b(adach_[a-z0-9_]+)\s*\(", hdr))
+    for name in sorted(hdeclared):
+        assert hasattr(raw, name), "libadacodec.so does not export %s" % name
+    assert hdeclared == set(host.HOST_SIGNATURES), hdeclared ^ set(host.HOST_SIGNATURES)
 
 
 def test_segment_desc_abi(adac):
