@@ -86,6 +86,7 @@ SIGNATURES = {
     "adac_size_in_bytes": (_u64, [_u64, _u8]),
     "adac_arena_words": (_u64, [_u64, _u8]),
     "adac_tile_values": (_u32, [_int]),
+    "adac_set_tuning": (_int, [C.c_char_p, _int]),
     "adac_ctx_create": (_int, [_int, _vp, _P(_vp)]),
     "adac_ctx_destroy": (None, [_vp]),
     "adac_ctx_sync": (_int, [_vp]),
@@ -170,6 +171,11 @@ def packed_words(count, w):
 
 def arena_words(count, w):
     return lib().adac_arena_words(count, w)
+
+
+def set_tuning(name, value):
+    if lib().adac_set_tuning(name.encode(), int(value)) != 0:
+        raise ValueError("unknown tuning knob %r" % name)
 
 
 def tile_values(dtype):

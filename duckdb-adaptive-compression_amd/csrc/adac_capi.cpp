@@ -116,6 +116,18 @@ extern "C" uint32_t adac_tile_values(int t) {
 	return ts ? adac::tile_values(ts) : 0;
 }
 
+extern "C" int adac_set_tuning(const char *name, int value) {
+	if (!name) return 1;
+	const std::string n(name);
+	if (n == "persistent_unpack") adac::g_tuning.persistent_unpack = value;
+	else if (n == "persistent_scan") adac::g_tuning.persistent_scan = value;
+	else if (n == "scan_tiles_per_wg" && value > 0) adac::g_tuning.scan_tiles_per_wg = value;
+	else if (n == "blocks_per_cu" && value > 0) adac::g_tuning.blocks_per_cu = value;
+	else if (n == "num_cus" && value > 0) adac::g_tuning.num_cus = value;
+	else return 1;
+	return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------

@@ -27,6 +27,17 @@ struct RangeArgs {
 	uint64_t out_off;
 };
 
+// Launch-shape knobs (adac_set_tuning): which kernel form the scan entry points use and how many persistent
+// workgroups are launched.  Defaults are the measured-best settings on MI355X.
+struct Tuning {
+	int persistent_unpack = 0;  // measured 5-15 % slower than one tile per workgroup (profiles/r01_ab_*.json)
+	int persistent_scan = 0;
+	int scan_tiles_per_wg = 8;  // tile-table entries per fused-scan workgroup (staged in runs sized by packed bytes)
+	int num_cus = 256;      // MI355X: 8 XCDs x 32 CUs
+	int blocks_per_cu = 8;  // 256-thread workgroups resident per CU (2048 threads, <= 16.5 KiB LDS each)
+};
+extern Tuning g_tuning;
+
 inline uint32_t tile_values(uint32_t type_size) {
 	return kTileBytes / type_size;
 }

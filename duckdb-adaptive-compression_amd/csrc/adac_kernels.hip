@@ -156,6 +156,60 @@ __device__ __forceinline__ void decode_rows(const uint32_t *lds32, uint32_t bit0
 	}
 }
 
+// Fast path for a FULL tile whose first row sits on a 16-byte boundary of the output (the common case: every
+// tile of a segment but its last, for 16-byte-aligned segment placement).  Static trip count, no row
+// predication, bit positions by one 24-bit multiply + adds (v_mul_lo_u32 is quarter rate), all LDS reads of a
+// round issued back to back.  sink(base, vals) always gets a complete chunk.
+template <typename U, bool WIDE, typename Sink>
+__device__ __forceinline__ void decode_full_tile(const uint32_t *lds32, uint32_t bit0, uint32_t w, uint64_t add,
+                                                 Sink &&sink) {
+	constexpr int K = 16 / (int)sizeof(U);
+	constexpr int TILE = kTileBytes / (int)sizeof(U);
+	constexpr int ROUNDS = TILE / (kWorkgroup * K);
+	const uint32_t mlo = WIDE ? 0xffffffffu : mask32(w);
+	const uint32_t mhi = WIDE ? mask32(w - 32u) : 0u;
+	const uint32_t add_lo = (uint32_t)add;
+	uint32_t bit = bit0 + __umul24(threadIdx.x * K, w); // < 2^24: at most 16384 rows x 64 bits
+	const uint32_t step = kWorkgroup * K * w;
+#pragma unroll
+	for (int r = 0; r < ROUNDS; r++) {
+		U vals[K];
+#pragma unroll
+		for (int j = 0; j < K; j++) {
+			uint32_t lo, hi;
+			read_field<WIDE>(lds32, bit + j * w, mlo, mhi, lo, hi);
+			if (sizeof(U) == 8) {
+				vals[j] = (U)((((uint64_t)hi << 32) | lo) + add);
+			} else {
+				vals[j] = (U)(lo + add_lo);
+			}
+		}
+		sink((int32_t)(r * kWorkgroup * K + threadIdx.x * K), vals, true);
+		bit += step;
+	}
+}
+
+// One staged tile -> sink, choosing the two/three-dword window and the full-tile fast path (both wave-uniform).
+template <typename U, typename Sink>
+__device__ __forceinline__ void decode_tile(const uint32_t *lds32, uint32_t bit0, uint32_t w, uint64_t add, uint32_t n,
+                                            uint32_t align, Sink &&sink) {
+	constexpr uint32_t TILE = kTileBytes / sizeof(U);
+	const bool fast = n == TILE && align == 0;
+	if (sizeof(U) == 8 && w > 32) {
+		if (fast) {
+			decode_full_tile<U, true>(lds32, bit0, w, add, sink);
+		} else {
+			decode_rows<U, true>(lds32, bit0, w, add, n, align, sink);
+		}
+	} else {
+		if (fast) {
+			decode_full_tile<U, false>(lds32, bit0, w, add, sink);
+		} else {
+			decode_rows<U, false>(lds32, bit0, w, add, n, align, sink);
+		}
+	}
+}
+
 __device__ __forceinline__ uint64_t effective_add(const adac_segment_desc &d) {
 	// product rule: the frame of reference is added back only where it was subtracted
 	return ((d.flags & ADAC_SEG_PACKED) && d.min != ADAC_NO_MIN) ? d.min : 0ull;
@@ -214,56 +268,248 @@ __global__ __launch_bounds__(kWorkgroup) void k_unpack(const adac_segment_desc *
 	const uint32_t align = (uint32_t)(elem0 & (K - 1));
 	StoreSink<U> sink {out + elem0, n};
 	const uint32_t *lds32 = reinterpret_cast<const uint32_t *>(lds);
-	if (sizeof(U) == 8 && w > 32) {
-		decode_rows<U, true>(lds32, bit0, w, add, n, align, sink);
-	} else {
-		decode_rows<U, false>(lds32, bit0, w, add, n, align, sink);
-	}
+	decode_tile<U>(lds32, bit0, w, add, n, align, sink);
 }
 
 // ---------------------------------------------------------------------------------------------
 // k_scan_sum / k_scan_count_eq — fused scan + aggregate, nothing materialised.
 // ---------------------------------------------------------------------------------------------
-template <typename U, int OP> // OP 0: sum, 1: count == key
-__global__ __launch_bounds__(kWorkgroup) void k_scan_agg(const adac_segment_desc *__restrict__ descs,
-                                                         const TileRef *__restrict__ tiles,
-                                                         const uint64_t *__restrict__ words, uint64_t key,
-                                                         uint64_t *__restrict__ result) {
-	constexpr int TILE = kTileBytes / (int)sizeof(U);
-	__shared__ uint4 lds[kTileBytes / 16 + 2];
-	__shared__ uint64_t partial[kWorkgroup / 64];
-	const TileCtx t = resolve_tile<TILE>(descs, tiles);
-	const uint32_t w = t.d.width;
-	const uint32_t bit0 = stage_packed(words + t.d.word_off, t.first, t.n, w, lds);
-	__syncthreads();
-	const uint64_t add = effective_add(t.d);
-	uint64_t acc = 0;
-	const uint32_t n = t.n;
-	const U k = (U)key;
-	auto sink = [&](int32_t base, const U *vals, bool full) {
-		constexpr int K = 16 / (int)sizeof(U);
+// Fused scans are sized by PACKED BYTES, not rows: a workgroup owns `group` consecutive tile-table entries and
+// stages as many whole tiles of one segment as fit the 16 KiB LDS image at that segment's width (8 tiles of
+// u64 at w <= 8, 2 at w = 32, ...), so ~16 KiB of HBM reads are in flight per workgroup at every width — at
+// one 2 KiB tile per stage (w = 8) a CU has too few bytes in flight to cover HBM latency.  The aggregate is
+// carried in registers across stages and flushed (wave reduce + one atomic per wave) once per segment run.
+template <typename U, bool WIDE, typename Sink>
+__device__ __forceinline__ void decode_run(const uint32_t *lds32, uint32_t bit0, uint32_t w, uint64_t add, uint32_t n,
+                                           Sink &&sink) {
+	constexpr int K = 16 / (int)sizeof(U);
+	constexpr uint32_t PER_ROUND = kWorkgroup * K;
+	if (n % PER_ROUND != 0) {
+		decode_rows<U, WIDE>(lds32, bit0, w, add, n, 0u, sink);
+		return;
+	}
+	const uint32_t mlo = WIDE ? 0xffffffffu : mask32(w);
+	const uint32_t mhi = WIDE ? mask32(w - 32u) : 0u;
+	const uint32_t add_lo = (uint32_t)add;
+	uint32_t bit = bit0 + __umul24(threadIdx.x * K, w);
+	const uint32_t step = PER_ROUND * w;
+	const uint32_t rounds = n / PER_ROUND;
+#pragma unroll 4
+	for (uint32_t r = 0; r < rounds; r++) {
+		U vals[K];
 #pragma unroll
 		for (int j = 0; j < K; j++) {
-			if (full || (uint32_t)(base + j) < n) {
-				acc += OP == 0 ? (uint64_t)vals[j] : (uint64_t)(vals[j] == k);
+			uint32_t lo, hi;
+			read_field<WIDE>(lds32, bit + j * w, mlo, mhi, lo, hi);
+			if (sizeof(U) == 8) {
+				vals[j] = (U)((((uint64_t)hi << 32) | lo) + add);
+			} else {
+				vals[j] = (U)(lo + add_lo);
 			}
 		}
-	};
+		sink(0, vals, true);
+		bit += step;
+	}
+}
+
+template <typename U, int OP> // OP 0: sum, 1: count == key
+__global__ __launch_bounds__(kWorkgroup) void k_scan_agg(const adac_segment_desc *__restrict__ descs,
+                                                         const TileRef *__restrict__ tiles, uint32_t ntiles,
+                                                         uint32_t group, const uint64_t *__restrict__ words,
+                                                         uint64_t key, uint64_t *__restrict__ result) {
+	constexpr uint32_t TILE = kTileBytes / sizeof(U);
+	__shared__ uint4 lds[kTileBytes / 16 + 2];
 	const uint32_t *lds32 = reinterpret_cast<const uint32_t *>(lds);
-	if (sizeof(U) == 8 && w > 32) {
-		decode_rows<U, true>(lds32, bit0, w, add, n, 0u, sink);
-	} else {
-		decode_rows<U, false>(lds32, bit0, w, add, n, 0u, sink);
-	}
-	acc = wave_sum(acc);
-	if ((threadIdx.x & 63) == 0) partial[threadIdx.x >> 6] = acc;
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		uint64_t s = 0;
+	uint32_t t = blockIdx.x * group;
+	const uint32_t hi = t + group < ntiles ? t + group : ntiles;
+	const U k = (U)key;
+	uint64_t acc = 0;
+	uint32_t seg = tiles[t].seg;
+	auto flush = [&](uint32_t to_seg) {
+		const uint64_t tot = wave_sum(acc);
+		if ((threadIdx.x & 63) == 0 && tot != 0) { // wrapping sums commute: one atomic per wave and run
+			atomicAdd(reinterpret_cast<unsigned long long *>(result + to_seg), (unsigned long long)tot);
+		}
+		acc = 0;
+	};
+	while (t < hi) {
+		const TileRef r = tiles[t];
+		if (r.seg != seg) { // wave-uniform
+			flush(seg);
+			seg = r.seg;
+		}
+		const adac_segment_desc d = descs[r.seg];
+		const uint32_t w = d.width;
+		uint32_t fit = (8u * kTileBytes) / (TILE * w); // whole tiles of this width per LDS image
+		fit = fit < 1u ? 1u : fit;
+		uint32_t run = 1;
+		while (run < fit && t + run < hi && tiles[t + run].seg == r.seg) run++;
+		const uint32_t left = d.count - r.first;
+		const uint32_t n = left < run * TILE ? left : run * TILE;
+		const uint32_t bit0 = stage_packed(words + d.word_off, r.first, n, w, lds);
+		__syncthreads();
+		auto sink = [&](int32_t base, const U *vals, bool full) {
+			constexpr int KK = 16 / (int)sizeof(U);
 #pragma unroll
-		for (int i = 0; i < kWorkgroup / 64; i++) s += partial[i];
-		atomicAdd(reinterpret_cast<unsigned long long *>(result + t.seg), (unsigned long long)s);
+			for (int j = 0; j < KK; j++) {
+				if (full || (uint32_t)(base + j) < n) {
+					acc += OP == 0 ? (uint64_t)vals[j] : (uint64_t)(vals[j] == k);
+				}
+			}
+		};
+		if (sizeof(U) == 8 && w > 32) {
+			decode_run<U, true>(lds32, bit0, w, effective_add(d), n, sink);
+		} else {
+			decode_run<U, false>(lds32, bit0, w, effective_add(d), n, sink);
+		}
+		__syncthreads(); // the image is rewritten by the next stage
+		t += run;
 	}
+	flush(seg);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Persistent forms of the two scan kernels.  A single tile's chain (tile table -> descriptor -> packed loads ->
+// barrier -> decode [-> wave reduce -> atomic]) is serial and its fixed part is as long as the decode of a
+// 16 KiB tile, so read-only scans leave HBM idle.  Here a workgroup owns a CONTIGUOUS run of tiles and keeps
+// the next tile's packed bytes in flight with LDS-DMA (global_load_lds_dwordx4: global -> LDS, no VGPRs)
+// into the other half of a double-buffered LDS image while it decodes the current half; one barrier per
+// tile; aggregates are carried in registers across the tiles of a segment and flushed once per segment.
+// (A first version prefetched into registers under `if (c < nchunks)`: hipcc put s_waitcnt vmcnt(0) behind
+// every conditional load — cdna_hip_programming.md §5 item 4(c) — and it ran 0.6x; LDS-DMA has no
+// destination register to merge, so nothing forces an early wait.)
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxChunks = kTileBytes / 16 + 2;
+
+struct TileJob {
+	const uint4 *src;  // first 16-byte chunk of the tile's packed bits
+	uint64_t elem0;    // element index of the tile's first row in the value buffer
+	uint64_t add;      // frame of reference to add back (0 if none)
+	uint32_t seg, n, w, bit0, nchunks;
+};
+
+template <int TILE>
+__device__ __forceinline__ TileJob make_job(const adac_segment_desc *__restrict__ descs,
+                                            const TileRef *__restrict__ tiles, uint32_t t,
+                                            const uint64_t *__restrict__ words) {
+	const TileRef r = tiles[t];
+	const adac_segment_desc d = descs[r.seg];
+	TileJob j;
+	j.seg = r.seg;
+	const uint32_t left = d.count - r.first;
+	j.n = left < (uint32_t)TILE ? left : (uint32_t)TILE;
+	j.w = d.width;
+	j.elem0 = d.val_off + r.first;
+	j.add = effective_add(d);
+	const uint64_t bitpos = (uint64_t)r.first * j.w;
+	j.bit0 = (uint32_t)(bitpos & 127);
+	j.nchunks = (j.bit0 + j.n * j.w + 127u) >> 7;
+	j.src = reinterpret_cast<const uint4 *>(words + d.word_off) + (bitpos >> 7);
+	return j;
+}
+
+using gptr_t = const __attribute__((address_space(1))) void *;
+using lptr_t = __attribute__((address_space(3))) void *;
+
+// Fire-and-forget copy of `nchunks` 16-byte chunks global -> LDS.  One wave instruction moves 1 KiB; its LDS
+// destination is the wave-uniform base + lane*16 (M0), so each wave copies 64 consecutive chunks per round.
+__device__ __forceinline__ void dma_chunks(const uint4 *__restrict__ src, uint32_t nchunks, uint4 *lds_buf) {
+	const uint32_t lane = threadIdx.x & 63u;
+	for (uint32_t base = threadIdx.x & ~63u; base < nchunks; base += kWorkgroup) {
+		const uint32_t c = base + lane;
+		if (c < nchunks) {
+			__builtin_amdgcn_global_load_lds((gptr_t)(src + c), (lptr_t)(lds_buf + base), 16, 0, 0);
+		}
+	}
+}
+
+__device__ __forceinline__ void tile_range(uint32_t ntiles, uint32_t &lo, uint32_t &hi) {
+	const uint32_t per = (ntiles + gridDim.x - 1) / gridDim.x;
+	lo = blockIdx.x * per;
+	hi = lo + per < ntiles ? lo + per : ntiles;
+}
+
+template <typename U>
+__global__ __launch_bounds__(kWorkgroup) void k_unpack_p(const adac_segment_desc *__restrict__ descs,
+                                                         const TileRef *__restrict__ tiles, uint32_t ntiles,
+                                                         const uint64_t *__restrict__ words, U *__restrict__ out) {
+	constexpr int TILE = kTileBytes / (int)sizeof(U);
+	constexpr uint32_t K = 16 / sizeof(U);
+	__shared__ uint4 lds[2][kMaxChunks];
+	uint32_t t, hi;
+	tile_range(ntiles, t, hi);
+	if (t >= hi) return;
+	TileJob cur = make_job<TILE>(descs, tiles, t, words);
+	dma_chunks(cur.src, cur.nchunks, lds[0]);
+	uint32_t buf = 0;
+	for (;;) {
+		__syncthreads(); // drains this wave's DMA (vmcnt) and publishes the image; also fences the other half
+		const bool more = t + 1 < hi;
+		TileJob nxt = cur;
+		if (more) {
+			nxt = make_job<TILE>(descs, tiles, t + 1, words);
+			dma_chunks(nxt.src, nxt.nchunks, lds[buf ^ 1]); // lands while this tile is decoded
+		}
+		const uint32_t *lds32 = reinterpret_cast<const uint32_t *>(lds[buf]);
+		StoreSink<U> sink {out + cur.elem0, cur.n};
+		const uint32_t align = (uint32_t)(cur.elem0 & (K - 1));
+		decode_tile<U>(lds32, cur.bit0, cur.w, cur.add, cur.n, align, sink);
+		if (!more) break;
+		cur = nxt;
+		buf ^= 1;
+		t++;
+	}
+}
+
+template <typename U, int OP> // OP 0: sum, 1: count == key
+__global__ __launch_bounds__(kWorkgroup) void k_scan_agg_p(const adac_segment_desc *__restrict__ descs,
+                                                           const TileRef *__restrict__ tiles, uint32_t ntiles,
+                                                           const uint64_t *__restrict__ words, uint64_t key,
+                                                           uint64_t *__restrict__ result) {
+	constexpr int TILE = kTileBytes / (int)sizeof(U);
+	__shared__ uint4 lds[2][kMaxChunks];
+	uint32_t t, hi;
+	tile_range(ntiles, t, hi);
+	if (t >= hi) return;
+	TileJob cur = make_job<TILE>(descs, tiles, t, words);
+	dma_chunks(cur.src, cur.nchunks, lds[0]);
+	uint32_t buf = 0;
+	const U k = (U)key;
+	uint64_t acc = 0; // this lane's share of the current segment's aggregate
+	auto flush = [&](uint32_t seg) {
+		const uint64_t tot = wave_sum(acc);
+		if ((threadIdx.x & 63) == 0 && tot != 0) { // wrapping sums commute: one atomic per wave and segment run
+			atomicAdd(reinterpret_cast<unsigned long long *>(result + seg), (unsigned long long)tot);
+		}
+		acc = 0;
+	};
+	for (;;) {
+		__syncthreads();
+		const bool more = t + 1 < hi;
+		TileJob nxt = cur;
+		if (more) {
+			nxt = make_job<TILE>(descs, tiles, t + 1, words);
+			dma_chunks(nxt.src, nxt.nchunks, lds[buf ^ 1]);
+		}
+		const uint32_t *lds32 = reinterpret_cast<const uint32_t *>(lds[buf]);
+		const uint32_t n = cur.n;
+		auto sink = [&](int32_t base, const U *vals, bool full) {
+			constexpr int KK = 16 / (int)sizeof(U);
+#pragma unroll
+			for (int j = 0; j < KK; j++) {
+				if (full || (uint32_t)(base + j) < n) {
+					acc += OP == 0 ? (uint64_t)vals[j] : (uint64_t)(vals[j] == k);
+				}
+			}
+		};
+		decode_tile<U>(lds32, cur.bit0, cur.w, cur.add, n, 0u, sink);
+		if (!more) break;
+		if (nxt.seg != cur.seg) flush(cur.seg); // wave-uniform
+		cur = nxt;
+		buf ^= 1;
+		t++;
+	}
+	flush(cur.seg);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -311,6 +557,26 @@ __global__ __launch_bounds__(kWorkgroup) void k_analyze(const adac_segment_desc 
 	const U *src = vals + t.elem0;
 	const uint32_t align = (uint32_t)(t.elem0 & (K - 1));
 	uint64_t mn = ~0ull, mx = 0;
+	if (t.n == (uint32_t)TILE && align == 0 && validity == nullptr) {
+		// full, aligned, all-valid tile: the four 16-byte loads of a lane are issued back to back
+		constexpr int ROUNDS = TILE / (kWorkgroup * K);
+		uint4 q[ROUNDS];
+#pragma unroll
+		for (int r = 0; r < ROUNDS; r++) {
+			q[r] = *reinterpret_cast<const uint4 *>(src + (r * kWorkgroup + threadIdx.x) * K);
+		}
+#pragma unroll
+		for (int r = 0; r < ROUNDS; r++) {
+			U v[K];
+			__builtin_memcpy(v, &q[r], 16);
+#pragma unroll
+			for (int j = 0; j < K; j++) {
+				const uint64_t x = (rule == ADAC_RULE_APPEND && sign_extend) ? (uint64_t)(int64_t)(S)v[j] : (uint64_t)v[j];
+				mn = x < mn ? x : mn;
+				mx = x > mx ? x : mx;
+			}
+		}
+	} else
 	for (uint32_t c = threadIdx.x; c * K < t.n + align; c += kWorkgroup) {
 		const int32_t base = (int32_t)(c * K) - (int32_t)align;
 		U v[K];
@@ -434,7 +700,7 @@ __global__ __launch_bounds__(kWorkgroup) void k_pack(const adac_segment_desc *__
                                                      uint64_t *__restrict__ words) {
 	constexpr int TILE = kTileBytes / (int)sizeof(U);
 	constexpr int K = 16 / (int)sizeof(U);
-	__shared__ U delta[TILE];
+	__shared__ __attribute__((aligned(16))) U delta[TILE];
 	const TileCtx t = resolve_tile<TILE>(descs, tiles);
 	const uint32_t w = t.d.width;
 	const bool packed = (t.d.flags & ADAC_SEG_PACKED) != 0;
@@ -442,6 +708,26 @@ __global__ __launch_bounds__(kWorkgroup) void k_pack(const adac_segment_desc *__
 	const U wmask = (U)mask64(w);
 	const U *src = vals + t.elem0;
 	const uint32_t align = (uint32_t)(t.elem0 & (K - 1));
+	if (t.n == (uint32_t)TILE && align == 0 && validity == nullptr) {
+		constexpr int ROUNDS = TILE / (kWorkgroup * K);
+		uint4 q[ROUNDS];
+#pragma unroll
+		for (int r = 0; r < ROUNDS; r++) {
+			q[r] = *reinterpret_cast<const uint4 *>(src + (r * kWorkgroup + threadIdx.x) * K);
+		}
+#pragma unroll
+		for (int r = 0; r < ROUNDS; r++) {
+			U v[K];
+			__builtin_memcpy(v, &q[r], 16);
+#pragma unroll
+			for (int j = 0; j < K; j++) {
+				v[j] = (U)(v[j] - (U)sub) & wmask;
+			}
+			uint4 o;
+			__builtin_memcpy(&o, v, 16);
+			*reinterpret_cast<uint4 *>(delta + (r * kWorkgroup + threadIdx.x) * K) = o; // ds_write_b128
+		}
+	} else
 	for (uint32_t c = threadIdx.x; c * K < t.n + align; c += kWorkgroup) {
 		const int32_t base = (int32_t)(c * K) - (int32_t)align;
 		U v[K];
@@ -508,7 +794,14 @@ hipError_t dispatch_size(uint32_t type_size, F &&f) {
 	}
 }
 
+unsigned persistent_grid(uint64_t ntiles) {
+	const uint64_t cap = (uint64_t)g_tuning.num_cus * (uint64_t)g_tuning.blocks_per_cu;
+	return (unsigned)(ntiles < cap ? ntiles : cap);
+}
+
 } // namespace
+
+Tuning g_tuning;
 
 hipError_t launch_minmax_init(hipStream_t s, uint64_t *d_minmax, uint64_t nseg) {
 	if (nseg == 0) return hipSuccess;
@@ -553,6 +846,12 @@ hipError_t launch_unpack(hipStream_t s, uint32_t type_size, const adac_segment_d
 	if (ntiles == 0) return hipSuccess;
 	return dispatch_size(type_size, [&](auto tag) {
 		using U = decltype(tag);
+		if (g_tuning.persistent_unpack) {
+			const unsigned grid = persistent_grid(ntiles);
+			hipLaunchKernelGGL(k_unpack_p<U>, dim3(grid), dim3(kWorkgroup), 0, s, d_descs, d_tiles, (uint32_t)ntiles,
+			                   d_words, static_cast<U *>(d_out));
+			return hipGetLastError();
+		}
 		hipLaunchKernelGGL((k_unpack<U, false>), dim3((unsigned)ntiles), dim3(kWorkgroup), 0, s, d_descs, d_tiles,
 		                   RangeArgs {}, d_words, static_cast<U *>(d_out));
 		return hipGetLastError();
@@ -588,8 +887,14 @@ hipError_t launch_scan_sum(hipStream_t s, uint32_t type_size, const adac_segment
 	if (ntiles == 0) return hipSuccess;
 	return dispatch_size(type_size, [&](auto tag) {
 		using U = decltype(tag);
-		hipLaunchKernelGGL((k_scan_agg<U, 0>), dim3((unsigned)ntiles), dim3(kWorkgroup), 0, s, d_descs, d_tiles,
-		                   d_words, (uint64_t)0, d_sums);
+		if (g_tuning.persistent_scan) {
+			hipLaunchKernelGGL((k_scan_agg_p<U, 0>), dim3(persistent_grid(ntiles)), dim3(kWorkgroup), 0, s, d_descs,
+			                   d_tiles, (uint32_t)ntiles, d_words, (uint64_t)0, d_sums);
+			return hipGetLastError();
+		}
+		const uint32_t per = (uint32_t)g_tuning.scan_tiles_per_wg;
+		hipLaunchKernelGGL((k_scan_agg<U, 0>), dim3((unsigned)((ntiles + per - 1) / per)), dim3(kWorkgroup), 0, s,
+		                   d_descs, d_tiles, (uint32_t)ntiles, per, d_words, (uint64_t)0, d_sums);
 		return hipGetLastError();
 	});
 }
@@ -600,8 +905,14 @@ hipError_t launch_scan_count_eq(hipStream_t s, uint32_t type_size, const adac_se
 	if (ntiles == 0) return hipSuccess;
 	return dispatch_size(type_size, [&](auto tag) {
 		using U = decltype(tag);
-		hipLaunchKernelGGL((k_scan_agg<U, 1>), dim3((unsigned)ntiles), dim3(kWorkgroup), 0, s, d_descs, d_tiles,
-		                   d_words, key, d_counts);
+		if (g_tuning.persistent_scan) {
+			hipLaunchKernelGGL((k_scan_agg_p<U, 1>), dim3(persistent_grid(ntiles)), dim3(kWorkgroup), 0, s, d_descs,
+			                   d_tiles, (uint32_t)ntiles, d_words, key, d_counts);
+			return hipGetLastError();
+		}
+		const uint32_t per = (uint32_t)g_tuning.scan_tiles_per_wg;
+		hipLaunchKernelGGL((k_scan_agg<U, 1>), dim3((unsigned)((ntiles + per - 1) / per)), dim3(kWorkgroup), 0, s,
+		                   d_descs, d_tiles, (uint32_t)ntiles, per, d_words, key, d_counts);
 		return hipGetLastError();
 	});
 }

@@ -103,6 +103,9 @@ uint64_t adac_size_in_bytes(uint64_t count, uint8_t width);
 uint64_t adac_arena_words(uint64_t count, uint8_t width);
 /* values per device tile for a type (16 KiB of decoded output) */
 uint32_t adac_tile_values(int physical_type);
+/* Launch-shape knobs for in-process A/B measurement: "persistent_unpack", "persistent_scan" (0/1),
+ * "blocks_per_cu", "num_cus".  Results never depend on them.  Returns 0 if the name is known. */
+int adac_set_tuning(const char *name, int value);
 
 /* ---------------------------------------------------------------------------------------------
  * Context and device memory.
