@@ -147,7 +147,7 @@ def run_sweep(adac, torch, ctx, rows, steps):
         dtype = np.dtype(dtype)
         counts = adac.appender_segment_counts(rows, dtype.itemsize)
         for w in widths:
-            vals = rng.integers(0, 2 ** w, size=rows, dtype=np.uint64).astype(dtype)
+            vals = rng.integers(0, 2 ** w, size=rows, dtype=np.uint32 if w <= 32 else np.uint64).astype(dtype)
             col = DeviceColumn(adac, torch, ctx, vals, counts, dtype)
             col.encode(adac.RULE_APPEND)
             col.unpack()
@@ -156,7 +156,8 @@ def run_sweep(adac, torch, ctx, rows, steps):
             assert col.verify_roundtrip()
             rd, wr, meta = algorithmic_bytes(descs, dtype.itemsize)
             ms = time_launches(ctx, col.unpack, steps)
-            d_sums = torch.zeros(len(counts), dtype=torch.int64, device=col.d_vals.device)
+            del col.d_vals  # the raw column is not needed by the scans
+            d_sums = torch.zeros(len(counts), dtype=torch.int64, device="cuda:%d" % ctx.device)
             torch.cuda.synchronize()
             col.layout.scan_sum(col.d_words, d_sums)
             ms_sum = time_launches(ctx, lambda: col.layout.scan_sum(col.d_words, d_sums), steps)
@@ -204,7 +205,7 @@ def main():
     ap.add_argument("--domain", type=int, default=2 ** 32 - 1)
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the CPU baseline (the box's CPU share per GPU)")
-    ap.add_argument("--sweep-rows", type=int, default=50_000_000)
+    ap.add_argument("--sweep-rows", type=int, default=200_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--backend", default=None)

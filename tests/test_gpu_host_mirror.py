@@ -209,7 +209,7 @@ def test_adaptive_policy_round(adac, oracle, host):
         db.policy_step(0.90)
         order = sorted(range(len(segs)), key=lambda i: (orcs[i].num_reads, i))
         for rank, i in enumerate(order):
-            if np.float32(rank + 1) / np.float32(len(order)) < 0.90:
+            if float(np.float32(rank + 1) / np.float32(len(order))) < 0.90:
                 orcs[i].compact()
             else:
                 orcs[i].uncompact()
