@@ -312,11 +312,121 @@ __device__ __forceinline__ void decode_run(const uint32_t *lds32, uint32_t bit0,
 	}
 }
 
+// ---------------------------------------------------------------------------------------------
+// Bit-width-templated, registers-only field walk for fused scans at W <= 32.  A lane owns whole 16-byte chunks
+// of the packed stream (one coalesced global_load_dwordx4 + the next dword: a 160-bit window), shifts the
+// window once so that its first field starts at bit 0, and then every field sits at a COMPILE-TIME position:
+// one v_bfe_u32 (or v_alignbit + and for a dword straddler) per value, no LDS, no barrier, no per-value
+// address arithmetic.  A lane decodes the fields that START in its chunk, so consecutive lanes cover
+// consecutive rows and nothing is decoded twice.
+// ---------------------------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ uint32_t field_of(const uint32_t (&nrm)[5], int j) {
+	constexpr uint32_t mask = W >= 32 ? 0xffffffffu : ((1u << W) - 1u);
+	const int pos = j * W, d = pos >> 5, sh = pos & 31;
+	if (sh + W <= 32) return (nrm[d] >> sh) & mask;
+	return __builtin_amdgcn_alignbit(nrm[d + 1], nrm[d], sh) & mask;
+}
+
+// Aggregate the fields of one chunk.  Exactness contract: the result equals aggregating the MATERIALISED
+// values T(field + min) as unsigned T.  For T = u64 that is linear (sum of fields + n*min, mod 2^64); for
+// narrower T the per-element truncation is kept.  Partial sums of a chunk stay in 32-bit registers whenever
+// MAXV fields of W bits cannot overflow them.
+template <int W, typename U, int OP>
+struct ChunkAgg {
+	static constexpr int MAXV = (128 + W - 1) / W;
+	static constexpr bool kFields32 = ((uint64_t)MAXV << W) <= 0xffffffffull; // MAXV fields fit a u32 sum
+	uint32_t p32 = 0;
+	uint64_t p64 = 0;
+	__device__ __forceinline__ void add(uint32_t f, uint32_t add_lo, uint32_t key_field) {
+		if (OP == 1) {
+			p32 += (f == key_field) ? 1u : 0u; // key_field = key - min, compared on the packed field
+		} else if (sizeof(U) == 8) {
+			if (kFields32) p32 += f; else p64 += f;
+		} else if (sizeof(U) == 4) {
+			p64 += (uint32_t)(f + add_lo);
+		} else {
+			p32 += (uint32_t)(U)(f + add_lo); // <= 32 values of <= 16 bits
+		}
+	}
+	__device__ __forceinline__ uint64_t total(uint32_t nv, uint64_t add) const {
+		if (OP == 0 && sizeof(U) == 8) return (uint64_t)p32 + p64 + (uint64_t)nv * add;
+		return (uint64_t)p32 + p64;
+	}
+};
+
+template <int W, typename U, int OP>
+__device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint32_t r0, uint32_t r1, uint32_t count,
+                                           uint64_t add, U key, uint64_t &acc) {
+	constexpr int MAXV = (128 + W - 1) / W;
+	constexpr uint32_t mask = W >= 32 ? 0xffffffffu : ((1u << W) - 1u);
+	const uint32_t c0 = (uint32_t)(((uint64_t)r0 * W) >> 7);       // r0 is a multiple of 128 rows
+	const uint32_t c1 = (uint32_t)(((uint64_t)r1 * W + 127) >> 7);
+	const uint32_t clast = (uint32_t)(((uint64_t)count * W + 127) >> 7) - 1; // last chunk holding data bits
+	const uint32_t add_lo = (uint32_t)add;
+	// T(field + min) == key  <=>  field == T(key - min), and a field never exceeds W bits
+	const U kf = (U)(key - (U)add);
+	if (OP == 1 && (uint64_t)kf > (uint64_t)mask) return;
+	const uint32_t key_field = (uint32_t)kf;
+	// software pipeline: the next chunk's loads are issued (unconditionally, index clamped into the segment)
+	// before the current chunk is decoded, so a wave always has a load in flight
+	uint32_t L = c0 + threadIdx.x;
+	if (L >= c1) return;
+	uint4 q = seg16[L];
+	uint32_t e = reinterpret_cast<const uint32_t *>(seg16 + (L < clast ? L + 1 : clast))[0];
+	for (; L < c1; L += kWorkgroup) {
+		const uint32_t Lp = L + kWorkgroup < clast ? L + kWorkgroup : clast;
+		const uint4 qn = seg16[Lp];
+		const uint32_t en = reinterpret_cast<const uint32_t *>(seg16 + (Lp < clast ? Lp + 1 : clast))[0];
+		const uint32_t i0 = (128u * L + (W - 1)) / W; // first row starting in this chunk
+		const uint32_t o0 = i0 * W - 128u * L;        // its bit offset, < W <= 32
+		uint32_t nrm[5];
+		nrm[0] = __builtin_amdgcn_alignbit(q.y, q.x, o0);
+		nrm[1] = __builtin_amdgcn_alignbit(q.z, q.y, o0);
+		nrm[2] = __builtin_amdgcn_alignbit(q.w, q.z, o0);
+		nrm[3] = __builtin_amdgcn_alignbit(e, q.w, o0);
+		nrm[4] = e >> o0;
+		q = qn;
+		e = en;
+		const uint32_t starting = (128u - o0 + (W - 1)) / W; // rows starting in the chunk: MAXV-1 or MAXV
+		const uint32_t lim = r1 > i0 ? r1 - i0 : 0u;
+		ChunkAgg<W, U, OP> agg;
+		uint32_t nv;
+		if (starting <= lim) { // interior chunk: only the last slot may be absent
+			nv = starting;
+#pragma unroll
+			for (int j = 0; j < MAXV - 1; j++) agg.add(field_of<W>(nrm, j), add_lo, key_field);
+			if (128 % W == 0 || starting == (uint32_t)MAXV) agg.add(field_of<W>(nrm, MAXV - 1), add_lo, key_field);
+		} else { // the run ends inside this chunk
+			nv = lim;
+#pragma unroll
+			for (int j = 0; j < MAXV; j++) {
+				if ((uint32_t)j < nv) agg.add(field_of<W>(nrm, j), add_lo, key_field);
+			}
+		}
+		acc += agg.total(nv, add);
+	}
+}
+
+template <typename U, int OP>
+__device__ __forceinline__ void scan_run_dispatch(uint32_t w, const uint4 *__restrict__ seg16, uint32_t r0,
+                                                  uint32_t r1, uint32_t count, uint64_t add, U key, uint64_t &acc) {
+	switch (w) {
+#define ADAC_W(N) case N: scan_run_w<N, U, OP>(seg16, r0, r1, count, add, key, acc); break;
+		ADAC_W(4) ADAC_W(5) ADAC_W(6) ADAC_W(7) ADAC_W(8) ADAC_W(9) ADAC_W(10) ADAC_W(11) ADAC_W(12) ADAC_W(13)
+		ADAC_W(14) ADAC_W(15) ADAC_W(16) ADAC_W(17) ADAC_W(18) ADAC_W(19) ADAC_W(20) ADAC_W(21) ADAC_W(22)
+		ADAC_W(23) ADAC_W(24) ADAC_W(25) ADAC_W(26) ADAC_W(27) ADAC_W(28) ADAC_W(29) ADAC_W(30) ADAC_W(31) ADAC_W(32)
+#undef ADAC_W
+	default: break;
+	}
+}
+
 template <typename U, int OP> // OP 0: sum, 1: count == key
 __global__ __launch_bounds__(kWorkgroup) void k_scan_agg(const adac_segment_desc *__restrict__ descs,
                                                          const TileRef *__restrict__ tiles, uint32_t ntiles,
-                                                         uint32_t group, const uint64_t *__restrict__ words,
-                                                         uint64_t key, uint64_t *__restrict__ result) {
+                                                         uint32_t group, int templated,
+                                                         const uint64_t *__restrict__ words, uint64_t key,
+                                                         uint64_t *__restrict__ result) {
 	constexpr uint32_t TILE = kTileBytes / sizeof(U);
 	__shared__ uint4 lds[kTileBytes / 16 + 2];
 	const uint32_t *lds32 = reinterpret_cast<const uint32_t *>(lds);
@@ -340,6 +450,17 @@ __global__ __launch_bounds__(kWorkgroup) void k_scan_agg(const adac_segment_desc
 		}
 		const adac_segment_desc d = descs[r.seg];
 		const uint32_t w = d.width;
+		if (templated && w >= 4 && w <= 32 && (uint64_t)d.count * w < (1ull << 31)) {
+			// width-templated register path: the whole run of this segment's tiles in this group, no LDS
+			uint32_t run = 1;
+			while (t + run < hi && tiles[t + run].seg == r.seg) run++;
+			const uint32_t left = d.count - r.first;
+			const uint32_t n = left < run * TILE ? left : run * TILE;
+			scan_run_dispatch<U, OP>(w, reinterpret_cast<const uint4 *>(words + d.word_off), r.first, r.first + n,
+			                         d.count, effective_add(d), k, acc);
+			t += run;
+			continue;
+		}
 		uint32_t fit = (8u * kTileBytes) / (TILE * w); // whole tiles of this width per LDS image
 		fit = fit < 1u ? 1u : fit;
 		uint32_t run = 1;
@@ -894,7 +1015,7 @@ hipError_t launch_scan_sum(hipStream_t s, uint32_t type_size, const adac_segment
 		}
 		const uint32_t per = (uint32_t)g_tuning.scan_tiles_per_wg;
 		hipLaunchKernelGGL((k_scan_agg<U, 0>), dim3((unsigned)((ntiles + per - 1) / per)), dim3(kWorkgroup), 0, s,
-		                   d_descs, d_tiles, (uint32_t)ntiles, per, d_words, (uint64_t)0, d_sums);
+		                   d_descs, d_tiles, (uint32_t)ntiles, per, g_tuning.templated_scan, d_words, (uint64_t)0, d_sums);
 		return hipGetLastError();
 	});
 }
@@ -912,7 +1033,7 @@ hipError_t launch_scan_count_eq(hipStream_t s, uint32_t type_size, const adac_se
 		}
 		const uint32_t per = (uint32_t)g_tuning.scan_tiles_per_wg;
 		hipLaunchKernelGGL((k_scan_agg<U, 1>), dim3((unsigned)((ntiles + per - 1) / per)), dim3(kWorkgroup), 0, s,
-		                   d_descs, d_tiles, (uint32_t)ntiles, per, d_words, key, d_counts);
+		                   d_descs, d_tiles, (uint32_t)ntiles, per, g_tuning.templated_scan, d_words, key, d_counts);
 		return hipGetLastError();
 	});
 }

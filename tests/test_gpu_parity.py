@@ -124,6 +124,25 @@ def test_every_width(adac, oracle, gpu_ctx, dtype):
     widths = descs["width"].tolist()
     assert widths[:tb - 1] == list(range(1, tb))  # w == tb cannot shrink: stays unpacked at tb
     assert widths[tb - 1] == tb and not (descs["flags"][tb - 1] & adac.SEG_PACKED)
+    # the fused scans at every width, in both kernel forms (width-templated registers / LDS image)
+    udt = np.dtype("u%d" % np.dtype(dtype).itemsize)
+    exp_sum = [int(v.view(udt).astype(np.uint64).sum(dtype=np.uint64)) for v in seg_vals]
+    keys = [seg_vals[5][3], seg_vals[tb // 2][0]]
+    d_res = gpu_ctx.alloc(len(counts) * 8)
+    try:
+        for templated in (1, 0):
+            adac.set_tuning("templated_scan", templated)
+            for group in (1, 3, 8):
+                adac.set_tuning("scan_tiles_per_wg", group)
+                lay.scan_sum(d_words, d_res)
+                assert d_res.download(np.uint64, len(counts)).tolist() == exp_sum, (templated, group)
+                for kv in keys:
+                    lay.scan_count_eq(d_words, int(np.array([kv]).view(udt)[0]), d_res)
+                    got = d_res.download(np.uint64, len(counts)).tolist()
+                    assert got == [int((v == kv).sum()) for v in seg_vals], (templated, group)
+    finally:
+        adac.set_tuning("templated_scan", 1)
+        adac.set_tuning("scan_tiles_per_wg", 8)
 
 
 def test_signed_and_mixed_sign(adac, oracle, gpu_ctx):
