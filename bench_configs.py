@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""Secondary harness (NOT the driver's bench.py): the reference's other workloads through the drop-in path,
+one JSON object on stdout.  Numbers go to profiles/ and DESIGN.md.
+
+  plugin_scan  benchmark/micro/succinct/sequential.cpp (SELECT * full scans): a column loaded and scanned through
+               the C++ host mirror in ColumnData::ScanVector's call pattern (2048-row Scan calls that return
+               rows to HOST memory), with and without the decoded-segment cache — the PCIe-inclusive path.
+  adaptive     zipf_over_time.cpp / zipf_distribution_diff_skews.cpp: segment-access traces with Zipf skew
+               0.5 / 1.0 / 2.0, one policy round per period: resident bytes, flips and re-encode rate.
+"""
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "duckdb-adaptive-compression_amd"
+
+
+def load(db, lay, dtype, values):
+    dtype = np.dtype(dtype)
+    row = 0
+    for count, cap in lay.appender_segments(len(values), dtype.itemsize):
+        s = db.create_segment(dtype, start=row, segment_size=cap * dtype.itemsize)
+        v = values[row:row + count]
+        for off in range(0, count, 2048):
+            s.append(v, offset=off, count=min(2048, count - off))
+        row += count
+
+
+def plugin_scan(host, lay, n=10_000_000):
+    values = np.arange(n, dtype=np.uint32)  # SuccinctSequentialInsert / C1 column
+    out = {"rows": n, "dtype": "u32", "vector_size": 2048, "variants": {}}
+    for name, cache in (("per_vector_device_decode", 0), ("decoded_segment_cache", 256 << 20)):
+        db = host.Database(0, arena_bytes=256 << 20, decoded_cache_bytes=cache)
+        t0 = time.perf_counter()
+        load(db, lay, np.uint32, values)
+        db.compact_all()
+        t_load = time.perf_counter() - t0
+        cs, sec_cold, rows = db.full_scan()
+        assert cs == n * (n - 1) // 2
+        cs, sec_warm, rows = db.full_scan()
+        out["variants"][name] = {
+            "load_and_compact_s": t_load, "total_data_size": db.total_data_size,
+            "cold_scan_rows_per_s": rows / sec_cold, "warm_scan_rows_per_s": rows / sec_warm,
+            "cache": db.cache_stats(),
+        }
+        db.close()
+    return out
+
+
+def adaptive(host, wl, nseg=400, rows=32767, periods=4):
+    rng = np.random.default_rng(3)
+    out = {"segments": nseg, "rows_per_segment": rows, "skews": {}}
+    data = [((i << 34) + rng.integers(0, 1 << (10 + i % 12), size=rows)).astype(np.uint64) for i in range(nseg)]
+    for skew in (0.5, 1.0, 2.0):
+        db = host.Database(0, adaptive=True, arena_bytes=512 << 20)
+        for i in range(nseg):
+            s = db.create_segment(np.uint64, start=i * rows)
+            for off in range(0, rows, 2048):
+                s.append(data[i], offset=off, count=min(2048, rows - off))
+        rec = {"raw_bytes": db.total_data_size, "periods": []}
+        for p in range(periods):
+            trace = wl.zipf_column(20000, np.uint32, domain=nseg, skew=skew, seed=500 + p, threads=1) - 1
+            t0 = time.perf_counter()
+            scanned = 0
+            for i in trace:
+                db.segments[int(i)].scan(0, 2048)
+                scanned += 2048
+            t_scan = time.perf_counter() - t0
+            before = [s.compacted for s in db.segments]
+            t0 = time.perf_counter()
+            db.policy_step(0.90)
+            t_policy = time.perf_counter() - t0
+            after = [s.compacted for s in db.segments]
+            packed = sum(1 for a, b in zip(before, after) if b and not a)
+            expanded = sum(1 for a, b in zip(before, after) if a and not b)
+            rec["periods"].append({
+                "lookups_per_s": len(trace) / t_scan, "scanned_rows_per_s": scanned / t_scan,
+                "resident_bytes": db.total_data_size, "arena_bytes": db.arena_used_bytes,
+                "policy_step_s": t_policy, "segments_packed": packed, "segments_expanded": expanded,
+                "reencode_raw_GBps": (packed + expanded) * rows * 8 / t_policy / 1e9 if t_policy > 0 else None,
+            })
+        out["skews"][str(skew)] = rec
+        db.close()
+    return out
+
+
+def main():
+    adac = importlib.import_module(PKG)
+    adac.build()
+    host = importlib.import_module(PKG + ".host")
+    lay = importlib.import_module(PKG + ".layout")
+    wl = importlib.import_module(PKG + ".workload")
+    res = {"plugin_scan": plugin_scan(host, lay), "adaptive": adaptive(host, wl)}
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

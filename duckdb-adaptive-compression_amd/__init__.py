@@ -97,6 +97,8 @@ SIGNATURES = {
     "adac_dev_memset": (_int, [_vp, _vp, _int, _sz]),
     "adac_memcpy_h2d": (_int, [_vp, _vp, _vp, _sz]),
     "adac_memcpy_d2h": (_int, [_vp, _vp, _vp, _sz]),
+    "adac_host_alloc_pinned": (_int, [_vp, _sz, _P(_vp)]),
+    "adac_host_free_pinned": (_int, [_vp, _vp]),
     "adac_timer_start": (_int, [_vp]),
     "adac_timer_stop": (_int, [_vp, _P(C.c_float)]),
     "adac_layout_create": (_int, [_vp, _int, _vp, _vp, _u64, _P(_vp)]),

@@ -223,6 +223,21 @@ extern "C" adac_status adac_memcpy_d2h(adac_ctx *c, void *dst, const void *d_src
 	return ADAC_OK;
 }
 
+extern "C" adac_status adac_host_alloc_pinned(adac_ctx *c, size_t bytes, void **ptr) {
+	if (!c || !ptr) return ADAC_ERR_INVALID_ARGUMENT;
+	ADAC_HIP(hipSetDevice(c->device));
+	ADAC_HIP(hipHostMalloc(ptr, bytes ? bytes : 16, hipHostMallocDefault));
+	return ADAC_OK;
+}
+
+extern "C" adac_status adac_host_free_pinned(adac_ctx *c, void *ptr) {
+	if (!c) return ADAC_ERR_INVALID_ARGUMENT;
+	if (!ptr) return ADAC_OK;
+	ADAC_HIP(hipSetDevice(c->device));
+	ADAC_HIP(hipHostFree(ptr));
+	return ADAC_OK;
+}
+
 extern "C" adac_status adac_timer_start(adac_ctx *c) {
 	if (!c) return ADAC_ERR_INVALID_ARGUMENT;
 	ADAC_HIP(hipSetDevice(c->device));

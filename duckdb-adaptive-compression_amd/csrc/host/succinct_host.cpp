@@ -47,7 +47,45 @@ SegmentPool::SegmentPool(int device, size_t arena_bytes) {
 	free_list[0] = arena_words;
 }
 
+const uint8_t *SegmentPool::CacheLookup(const void *key) {
+	auto it = cache.find(key);
+	if (it == cache.end()) {
+		cache_misses++;
+		return nullptr;
+	}
+	cache_hits++;
+	it->second.stamp = ++cache_clock;
+	return it->second.data;
+}
+
+uint8_t *SegmentPool::CacheInsert(const void *key, size_t bytes) {
+	if (bytes > cache_capacity) return nullptr;
+	while (cache_used + bytes > cache_capacity && !cache.empty()) {
+		auto victim = cache.begin();
+		for (auto it = cache.begin(); it != cache.end(); ++it) {
+			if (it->second.stamp < victim->second.stamp) victim = it;
+		}
+		adac_host_free_pinned(ctx, victim->second.data);
+		cache_used -= victim->second.bytes;
+		cache.erase(victim);
+	}
+	void *p = nullptr;
+	if (adac_host_alloc_pinned(ctx, bytes, &p) != ADAC_OK) return nullptr;
+	cache[key] = CacheEntry {static_cast<uint8_t *>(p), bytes, ++cache_clock};
+	cache_used += bytes;
+	return static_cast<uint8_t *>(p);
+}
+
+void SegmentPool::CacheDrop(const void *key) {
+	auto it = cache.find(key);
+	if (it == cache.end()) return;
+	adac_host_free_pinned(ctx, it->second.data);
+	cache_used -= it->second.bytes;
+	cache.erase(it);
+}
+
 SegmentPool::~SegmentPool() {
+	for (auto &e : cache) adac_host_free_pinned(ctx, e.second.data);
 	if (d_staging) adac_dev_free(ctx, d_staging);
 	if (d_staging2) adac_dev_free(ctx, d_staging2);
 	if (d_arena) adac_dev_free(ctx, d_arena);
@@ -185,6 +223,7 @@ CompressionFunction UncompressedFun::GetFunction(PhysicalType data_type) {
 
 DatabaseInstance::DatabaseInstance(int device, const DBConfig &config_p, size_t arena_bytes)
     : config(config_p), pool(device, arena_bytes), catalog(*this) {
+	pool.cache_capacity = config.decoded_cache_bytes;
 }
 
 const CompressionFunction *DatabaseInstance::GetCompressionFunction(CompressionType type, PhysicalType data_type) {
@@ -247,6 +286,10 @@ ColumnSegment::~ColumnSegment() {
 		db.pool.Free(word_off, arena_words);
 	}
 	DropRef(this);
+	if (db.pool.cache_capacity) {
+		std::lock_guard<std::mutex> g(db.pool.lock);
+		db.pool.CacheDrop(this);
+	}
 }
 
 idx_t ColumnSegment::GetDataSize() const {
@@ -291,6 +334,24 @@ void ColumnSegment::ScanRows(idx_t start_row, idx_t scan_count, data_ptr_t targe
 	if (function->type == CompressionType::COMPRESSION_SUCCINCT && packed_on_device) {
 		SegmentDeviceRef ref = GetRef(this);
 		std::lock_guard<std::mutex> pg(db.pool.lock);
+		if (db.pool.cache_capacity) {
+			// vector-serving cache: decode the WHOLE segment once, serve this and the following vectors by memcpy
+			const uint8_t *hit = db.pool.CacheLookup(this);
+			if (!hit) {
+				uint8_t *block = db.pool.CacheInsert(this, count * type_size);
+				if (block) {
+					void *d_all = db.pool.Staging(count * type_size);
+					Check(adac_unpack_range(ref.layout->layout, db.pool.d_arena, ref.index, 0, count, d_all, 0),
+					      "adac_unpack_range");
+					Check(adac_memcpy_d2h(db.pool.ctx, block, d_all, count * type_size), "adac_memcpy_d2h");
+					hit = block;
+				}
+			}
+			if (hit) {
+				std::memcpy(target, hit + start_row * type_size, scan_count * type_size);
+				return;
+			}
+		}
 		void *d_out = db.pool.Staging(scan_count * type_size);
 		Check(adac_unpack_range(ref.layout->layout, db.pool.d_arena, ref.index, start_row, scan_count, d_out, 0),
 		      "adac_unpack_range");
@@ -503,6 +564,7 @@ void ColumnSegment::Uncompact() {
 			Check(adac_memcpy_d2h(db.pool.ctx, raw.data(), d_out, count * type_size), "adac_memcpy_d2h");
 		}
 		db.pool.Free(word_off, arena_words);
+		db.pool.CacheDrop(this);
 		packed_on_device = false;
 		DropRef(this);
 	}
@@ -670,6 +732,61 @@ extern "C" adach_db *adach_db_create(int device, int succinct_enabled, int adapt
 		h = new adach_db {std::move(db)};
 	});
 	return h;
+}
+
+extern "C" adach_db *adach_db_create_cached(int device, int succinct_enabled, int adaptive, int padded,
+                                            uint64_t arena_bytes, uint64_t decoded_cache_bytes) {
+	adach_db *h = nullptr;
+	Guard([&]() {
+		DBConfig cfg;
+		cfg.succinct_enabled = succinct_enabled != 0;
+		cfg.adaptive_succinct_compression_enabled = adaptive != 0;
+		cfg.succinct_padded_to_next_byte_enabled = padded != 0;
+		cfg.decoded_cache_bytes = decoded_cache_bytes;
+		auto db = std::unique_ptr<DatabaseInstance>(new DatabaseInstance(device, cfg, arena_bytes));
+		h = new adach_db {std::move(db)};
+	});
+	return h;
+}
+
+extern "C" void adach_db_cache_stats(adach_db *h, uint64_t *hits, uint64_t *misses, uint64_t *bytes) {
+	std::lock_guard<std::mutex> g(h->db->pool.lock);
+	if (hits) *hits = h->db->pool.cache_hits;
+	if (misses) *misses = h->db->pool.cache_misses;
+	if (bytes) *bytes = h->db->pool.cache_used;
+}
+
+// Full scan of a list of segments in the engine's call pattern — ColumnSegment::Scan on vector_size-row vectors
+// (ColumnData::ScanVector, column_data.cpp:92-139) — timed on the host; checksum = wrapping sum of all rows.
+extern "C" int adach_full_scan(adach_segment **segs, uint64_t nseg, uint64_t vector_size, uint64_t *checksum,
+                               double *seconds, uint64_t *rows_out) {
+	return Guard([&]() {
+		std::vector<uint8_t> vec(vector_size * 8 + 64);
+		uint64_t sum = 0, rows = 0;
+		auto t0 = std::chrono::steady_clock::now();
+		for (uint64_t i = 0; i < nseg; i++) {
+			ColumnSegment &s = *segs[i]->seg;
+			for (idx_t r = 0; r < s.count; r += vector_size) {
+				idx_t c = std::min<idx_t>(vector_size, s.count - r);
+				ColumnScanState st;
+				st.row_index = s.start + r;
+				Vector v;
+				v.data = vec.data();
+				s.Scan(st, c, v, 0, true);
+				const idx_t ts = s.type_size;
+				for (idx_t k = 0; k < c; k++) { // the consumer touches every value
+					uint64_t x = 0;
+					std::memcpy(&x, vec.data() + k * ts, ts);
+					sum += x;
+				}
+				rows += c;
+			}
+		}
+		auto t1 = std::chrono::steady_clock::now();
+		if (checksum) *checksum = sum;
+		if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
+		if (rows_out) *rows_out = rows;
+	});
 }
 
 extern "C" void adach_db_destroy(adach_db *h) {

@@ -54,6 +54,10 @@ struct DBConfig {
 	bool succinct_extract_prefix_enabled = true; // read only by the reference's dead SuccinctScanAndCompact
 	bool succinct_padded_to_next_byte_enabled = false;
 	bool adaptive_succinct_compression_enabled = false;
+	// Not in the reference: bytes of page-locked host memory used to keep whole DECODED segments, so the
+	// engine's 2048-row scan_vector calls (ColumnData::ScanVector, src/storage/table/column_data.cpp:92-139)
+	// cost one device decode + one PCIe copy per SEGMENT instead of per vector. 0 = off.
+	uint64_t decoded_cache_bytes = 0;
 };
 
 // The slice of duckdb::UnifiedVectorFormat the append slot reads (data, selection vector, validity mask).
@@ -118,6 +122,18 @@ public:
 	void *Staging(size_t bytes);   // device scratch, grown on demand
 	void *Staging2(size_t bytes);  // second device scratch (validity)
 	std::mutex lock;               // serialises device work of this pool (one stream)
+
+	// Decoded-segment cache (page-locked host blocks, LRU by bytes).  Guarded by `lock`.
+	struct CacheEntry {
+		uint8_t *data = nullptr;
+		size_t bytes = 0;
+		uint64_t stamp = 0;
+	};
+	uint64_t cache_capacity = 0, cache_used = 0, cache_clock = 0, cache_hits = 0, cache_misses = 0;
+	std::unordered_map<const void *, CacheEntry> cache;
+	const uint8_t *CacheLookup(const void *key);
+	uint8_t *CacheInsert(const void *key, size_t bytes); // evicts least-recently-used entries; nullptr if too big
+	void CacheDrop(const void *key);
 
 private:
 	std::map<uint64_t, uint64_t> free_list; // offset -> length

@@ -14,6 +14,9 @@ HOST_SIGNATURES = {
     "adach_type_is_supported": (_int, [_int]),
     "adach_db_create": (_vp, [_int, _int, _int, _int, _u64]),
     "adach_db_destroy": (None, [_vp]),
+    "adach_db_create_cached": (_vp, [_int, _int, _int, _int, _u64, _u64]),
+    "adach_db_cache_stats": (None, [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
+    "adach_full_scan": (_int, [C.POINTER(_vp), _u64, _u64, C.POINTER(_u64), C.POINTER(C.c_double), C.POINTER(_u64)]),
     "adach_db_data_size": (_i64, [_vp]),
     "adach_db_arena_used_bytes": (_u64, [_vp]),
     "adach_segment_create": (_vp, [_vp, _int, _u64, _u64]),
@@ -69,8 +72,10 @@ def _p(a):
 class Database:
     """DBConfig flags + one GPU segment pool + the ColumnSegmentCatalog."""
 
-    def __init__(self, device=0, succinct_enabled=True, adaptive=False, padded=False, arena_bytes=1 << 30):
-        self._h = hlib().adach_db_create(device, int(succinct_enabled), int(adaptive), int(padded), arena_bytes)
+    def __init__(self, device=0, succinct_enabled=True, adaptive=False, padded=False, arena_bytes=1 << 30,
+                 decoded_cache_bytes=0):
+        self._h = hlib().adach_db_create_cached(device, int(succinct_enabled), int(adaptive), int(padded), arena_bytes,
+                                                decoded_cache_bytes)
         if not self._h:
             raise HostError("adach_db_create: %s" % hlib().adach_last_error().decode())
         self.segments = []
@@ -95,6 +100,21 @@ class Database:
         s = Segment(self, dtype, start, segment_size)
         self.segments.append(s)
         return s
+
+    def cache_stats(self):
+        h, m, b = _u64(), _u64(), _u64()
+        hlib().adach_db_cache_stats(self._h, C.byref(h), C.byref(m), C.byref(b))
+        return {"hits": h.value, "misses": m.value, "bytes": b.value}
+
+    def full_scan(self, segments=None, vector_size=2048):
+        """Scan every row of `segments` in vector_size-row ColumnSegment::Scan calls (C++ loop, timed on the
+        host).  Returns (checksum, seconds, rows)."""
+        segments = self.segments if segments is None else segments
+        arr = (_vp * len(segments))(*[s._h for s in segments])
+        cs, sec, rows = _u64(), C.c_double(), _u64()
+        _ok(hlib().adach_full_scan(arr, len(segments), vector_size, C.byref(cs), C.byref(sec), C.byref(rows)),
+            "full_scan")
+        return cs.value, sec.value, rows.value
 
     def compact_all(self):
         _ok(hlib().adach_catalog_compact_all(self._h), "CompactAllSegments")

@@ -125,6 +125,10 @@ adac_status adac_dev_memset(adac_ctx *ctx, void *d_ptr, int byte, size_t bytes);
 adac_status adac_memcpy_h2d(adac_ctx *ctx, void *d_dst, const void *src, size_t bytes); /* blocking */
 adac_status adac_memcpy_d2h(adac_ctx *ctx, void *dst, const void *d_src, size_t bytes); /* blocking */
 
+/* Page-locked host memory for staging (hipHostMalloc): D2H/H2D copies of it run at PCIe line rate. */
+adac_status adac_host_alloc_pinned(adac_ctx *ctx, size_t bytes, void **ptr);
+adac_status adac_host_free_pinned(adac_ctx *ctx, void *ptr);
+
 /* HIP-event stopwatch on the ctx stream (for measuring kernels where they are launched). */
 adac_status adac_timer_start(adac_ctx *ctx);
 adac_status adac_timer_stop(adac_ctx *ctx, float *elapsed_ms); /* records, synchronises, reads */

@@ -32,6 +32,15 @@ int adach_type_is_supported(int physical_type);
 
 /* arena_bytes: capacity of this GPU's packed-segment arena. NULL on failure (e.g. no device). */
 adach_db *adach_db_create(int device, int succinct_enabled, int adaptive, int padded, uint64_t arena_bytes);
+/* same, with `decoded_cache_bytes` of page-locked host memory holding whole decoded segments so that the
+ * engine's 2048-row scan_vector calls cost one device decode + one PCIe copy per segment (0 = off) */
+adach_db *adach_db_create_cached(int device, int succinct_enabled, int adaptive, int padded, uint64_t arena_bytes,
+                                 uint64_t decoded_cache_bytes);
+void adach_db_cache_stats(adach_db *db, uint64_t *hits, uint64_t *misses, uint64_t *bytes);
+/* Full scan of segs[0..nseg) the way ColumnData::ScanVector drives the codec (vector_size rows per
+ * ColumnSegment::Scan call), timed on the host; checksum = wrapping sum of every scanned row. */
+int adach_full_scan(adach_segment **segs, uint64_t nseg, uint64_t vector_size, uint64_t *checksum, double *seconds,
+                    uint64_t *rows);
 void adach_db_destroy(adach_db *db);
 int64_t adach_db_data_size(adach_db *db);          /* BufferManager::GetDataSize analogue */
 uint64_t adach_db_arena_used_bytes(adach_db *db);  /* HBM actually held by packed segments */

@@ -271,3 +271,59 @@ def test_background_thread_compacts_while_scanning(adac, host):
         assert any(s.compacted for s, _ in cols)
     finally:
         db.close()
+
+
+def test_decoded_segment_cache_serves_vectors(adac, host):
+    """with the vector-serving cache on, a full scan in the engine's call pattern decodes each
+    segment once on the device (one miss per segment) and serves the other vectors from pinned host memory;
+    results are identical with the cache off, and representation flips invalidate it."""
+    rng = np.random.default_rng(12)
+    n = 400_000
+    values = (1 << 20) + rng.integers(0, 1 << 14, size=n).astype(np.uint32)
+    results = {}
+    for cache_bytes in (0, 8 << 20):
+        db = host.Database(0, arena_bytes=32 << 20, decoded_cache_bytes=cache_bytes)
+        try:
+            row = 0
+            for count, cap in lay_mod(adac).appender_segments(n, 4):
+                s = db.create_segment(np.uint32, start=row, segment_size=cap * 4)
+                for off in range(0, count, 2048):
+                    s.append(values[row:row + count], offset=off, count=min(2048, count - off))
+                row += count
+            db.compact_all()
+            cs, sec, rows = db.full_scan()
+            assert rows == n and cs == int(values.astype(np.uint64).sum())
+            cs2, _, _ = db.full_scan()
+            assert cs2 == cs
+            st = db.cache_stats()
+            results[cache_bytes] = st
+            if cache_bytes:
+                nseg = len(db.segments)
+                assert st["misses"] == nseg            # one device decode per segment, second pass all hits
+                assert st["hits"] >= 2 * (n // 2048) - nseg
+                assert 0 < st["bytes"] <= cache_bytes
+                # a flip drops the cached image: uncompact + new values + recompact must be visible
+                s = db.segments[1]
+                before = s.scan(0, 2048).copy()
+                s.uncompact()
+                assert not s.compacted
+                s.compact()
+                assert np.array_equal(s.scan(0, 2048), before)
+                # eviction: a cache smaller than the working set still returns correct rows
+        finally:
+            db.close()
+    assert results[0] == {"hits": 0, "misses": 0, "bytes": 0}
+    small = host.Database(0, arena_bytes=32 << 20, decoded_cache_bytes=300_000)  # holds one segment at a time
+    try:
+        row = 0
+        for count, cap in lay_mod(adac).appender_segments(n, 4):
+            s = small.create_segment(np.uint32, start=row, segment_size=cap * 4)
+            for off in range(0, count, 2048):
+                s.append(values[row:row + count], offset=off, count=min(2048, count - off))
+            row += count
+        small.compact_all()
+        cs, _, rows = small.full_scan()
+        assert rows == n and cs == int(values.astype(np.uint64).sum())
+        assert small.cache_stats()["bytes"] <= 300_000
+    finally:
+        small.close()
