@@ -138,15 +138,17 @@ def cpu_baseline(orc, col, vals, seconds, threads):
     }
 
 
-def run_sweep(adac, torch, ctx, rows, steps):
+def run_sweep(adac, torch, ctx, base_rows, steps):
     """Decode + fused-scan throughput for uniformly distributed values at widths 8..32 (the north star's
     '8-32-bit unpack' range), uint64 and uint32 outputs."""
     out = []
     rng = np.random.default_rng(7)
     for dtype, widths in ((np.uint64, (8, 13, 16, 20, 24, 32)), (np.uint32, (8, 13, 16, 20, 24))):
         dtype = np.dtype(dtype)
-        counts = adac.appender_segment_counts(rows, dtype.itemsize)
         for w in widths:
+            # the packed column must not fit the 256 MiB Infinity Cache, or the fused scan reads it from there
+            rows = max(base_rows, int(400e6 * 8 / w))
+            counts = adac.appender_segment_counts(rows, dtype.itemsize)
             vals = rng.integers(0, 2 ** w, size=rows, dtype=np.uint32 if w <= 32 else np.uint64).astype(dtype)
             col = DeviceColumn(adac, torch, ctx, vals, counts, dtype)
             col.encode(adac.RULE_APPEND)
@@ -162,7 +164,7 @@ def run_sweep(adac, torch, ctx, rows, steps):
             col.layout.scan_sum(col.d_words, d_sums)
             ms_sum = time_launches(ctx, lambda: col.layout.scan_sum(col.d_words, d_sums), steps)
             out.append({
-                "dtype": "u%d" % (8 * dtype.itemsize), "width": w,
+                "dtype": "u%d" % (8 * dtype.itemsize), "width": w, "rows": rows,
                 "widths_seen": sorted(set(descs["width"].tolist())),
                 "decode_values_per_s": rows / (ms * 1e-3),
                 "decode_total_GBps": (rd + wr + meta) / (ms * 1e-3) / 1e9,

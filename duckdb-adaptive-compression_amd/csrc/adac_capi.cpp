@@ -121,6 +121,7 @@ extern "C" int adac_set_tuning(const char *name, int value) {
 	const std::string n(name);
 	if (n == "persistent_unpack") adac::g_tuning.persistent_unpack = value;
 	else if (n == "persistent_scan") adac::g_tuning.persistent_scan = value;
+	else if (n == "scan_probe") adac::g_tuning.scan_probe = value;
 	else if (n == "templated_scan") adac::g_tuning.templated_scan = value;
 	else if (n == "scan_tiles_per_wg" && value > 0) adac::g_tuning.scan_tiles_per_wg = value;
 	else if (n == "blocks_per_cu" && value > 0) adac::g_tuning.blocks_per_cu = value;

@@ -32,8 +32,9 @@ struct RangeArgs {
 struct Tuning {
 	int persistent_unpack = 0;  // measured 5-15 % slower than one tile per workgroup (profiles/r01_ab_*.json)
 	int persistent_scan = 0;
+	int scan_probe = 0;         // diagnostic: fused-scan loop + loads only (no field walk)
 	int templated_scan = 1;     // width-templated register path of the fused scans for 4 <= w <= 32
-	int scan_tiles_per_wg = 8;  // tile-table entries per fused-scan workgroup (staged in runs sized by packed bytes)
+	int scan_tiles_per_wg = 16; // tile-table entries per fused-scan workgroup
 	int num_cus = 256;      // MI355X: 8 XCDs x 32 CUs
 	int blocks_per_cu = 8;  // 256-thread workgroups resident per CU (2048 threads, <= 16.5 KiB LDS each)
 };

@@ -388,6 +388,10 @@ __device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint
 		nrm[4] = e >> o0;
 		q = qn;
 		e = en;
+		if (OP == 2) { // load-only probe (diagnostic): same loop and loads, no field walk
+			acc += nrm[0] + nrm[1] + nrm[2] + nrm[3] + nrm[4];
+			continue;
+		}
 		const uint32_t starting = (128u - o0 + (W - 1)) / W; // rows starting in the chunk: MAXV-1 or MAXV
 		const uint32_t lim = r1 > i0 ? r1 - i0 : 0u;
 		ChunkAgg<W, U, OP> agg;
@@ -452,9 +456,11 @@ __global__ __launch_bounds__(kWorkgroup) void k_scan_agg(const adac_segment_desc
 		const uint32_t w = d.width;
 		if (templated && w >= 4 && w <= 32 && (uint64_t)d.count * w < (1ull << 31)) {
 			// width-templated register path: the whole run of this segment's tiles in this group, no LDS
-			uint32_t run = 1;
-			while (t + run < hi && tiles[t + run].seg == r.seg) run++;
+			// tiles of one segment are consecutive table entries, so the run length is arithmetic (walking the
+			// table entry by entry costs one dependent scalar load per tile: measured 3.0 -> TB/s-bound)
 			const uint32_t left = d.count - r.first;
+			const uint32_t tiles_left = (left + TILE - 1) / TILE;
+			const uint32_t run = tiles_left < hi - t ? tiles_left : hi - t;
 			const uint32_t n = left < run * TILE ? left : run * TILE;
 			scan_run_dispatch<U, OP>(w, reinterpret_cast<const uint4 *>(words + d.word_off), r.first, r.first + n,
 			                         d.count, effective_add(d), k, acc);
@@ -463,9 +469,10 @@ __global__ __launch_bounds__(kWorkgroup) void k_scan_agg(const adac_segment_desc
 		}
 		uint32_t fit = (8u * kTileBytes) / (TILE * w); // whole tiles of this width per LDS image
 		fit = fit < 1u ? 1u : fit;
-		uint32_t run = 1;
-		while (run < fit && t + run < hi && tiles[t + run].seg == r.seg) run++;
 		const uint32_t left = d.count - r.first;
+		const uint32_t tiles_left = (left + TILE - 1) / TILE;
+		uint32_t run = tiles_left < hi - t ? tiles_left : hi - t;
+		run = run < fit ? run : fit;
 		const uint32_t n = left < run * TILE ? left : run * TILE;
 		const uint32_t bit0 = stage_packed(words + d.word_off, r.first, n, w, lds);
 		__syncthreads();
@@ -474,7 +481,7 @@ __global__ __launch_bounds__(kWorkgroup) void k_scan_agg(const adac_segment_desc
 #pragma unroll
 			for (int j = 0; j < KK; j++) {
 				if (full || (uint32_t)(base + j) < n) {
-					acc += OP == 0 ? (uint64_t)vals[j] : (uint64_t)(vals[j] == k);
+					acc += OP == 1 ? (uint64_t)(vals[j] == k) : (uint64_t)vals[j];
 				}
 			}
 		};
@@ -1014,6 +1021,11 @@ hipError_t launch_scan_sum(hipStream_t s, uint32_t type_size, const adac_segment
 			return hipGetLastError();
 		}
 		const uint32_t per = (uint32_t)g_tuning.scan_tiles_per_wg;
+		if (g_tuning.scan_probe) { // diagnostic: the scan's loop and loads without the field walk (result meaningless)
+			hipLaunchKernelGGL((k_scan_agg<U, 2>), dim3((unsigned)((ntiles + per - 1) / per)), dim3(kWorkgroup), 0, s,
+			                   d_descs, d_tiles, (uint32_t)ntiles, per, 1, d_words, (uint64_t)0, d_sums);
+			return hipGetLastError();
+		}
 		hipLaunchKernelGGL((k_scan_agg<U, 0>), dim3((unsigned)((ntiles + per - 1) / per)), dim3(kWorkgroup), 0, s,
 		                   d_descs, d_tiles, (uint32_t)ntiles, per, g_tuning.templated_scan, d_words, (uint64_t)0, d_sums);
 		return hipGetLastError();

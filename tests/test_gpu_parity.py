@@ -132,7 +132,7 @@ def test_every_width(adac, oracle, gpu_ctx, dtype):
     try:
         for templated in (1, 0):
             adac.set_tuning("templated_scan", templated)
-            for group in (1, 3, 8):
+            for group in (1, 3, 16):
                 adac.set_tuning("scan_tiles_per_wg", group)
                 lay.scan_sum(d_words, d_res)
                 assert d_res.download(np.uint64, len(counts)).tolist() == exp_sum, (templated, group)
@@ -142,7 +142,7 @@ def test_every_width(adac, oracle, gpu_ctx, dtype):
                     assert got == [int((v == kv).sum()) for v in seg_vals], (templated, group)
     finally:
         adac.set_tuning("templated_scan", 1)
-        adac.set_tuning("scan_tiles_per_wg", 8)
+        adac.set_tuning("scan_tiles_per_wg", 16)
 
 
 def test_signed_and_mixed_sign(adac, oracle, gpu_ctx):
