@@ -152,26 +152,8 @@ struct LayoutHandle {
 	}
 };
 
-// per-segment side table (kept out of the header: it holds C-ABI handles)
-struct SegmentDeviceRef {
-	std::shared_ptr<LayoutHandle> layout;
-	uint64_t index = 0;
-};
-static std::mutex g_ref_lock;
-static std::unordered_map<const ColumnSegment *, SegmentDeviceRef> g_refs;
-
-static SegmentDeviceRef GetRef(const ColumnSegment *s) {
-	std::lock_guard<std::mutex> g(g_ref_lock);
-	auto it = g_refs.find(s);
-	return it == g_refs.end() ? SegmentDeviceRef() : it->second;
-}
-static void SetRef(const ColumnSegment *s, SegmentDeviceRef r) {
-	std::lock_guard<std::mutex> g(g_ref_lock);
-	g_refs[s] = std::move(r);
-}
-static void DropRef(const ColumnSegment *s) {
-	std::lock_guard<std::mutex> g(g_ref_lock);
-	g_refs.erase(s);
+static adac_layout *LayoutOf(const std::shared_ptr<void> &handle) {
+	return static_cast<LayoutHandle *>(handle.get())->layout;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -285,7 +267,6 @@ ColumnSegment::~ColumnSegment() {
 		std::lock_guard<std::mutex> g(db.pool.lock);
 		db.pool.Free(word_off, arena_words);
 	}
-	DropRef(this);
 	if (db.pool.cache_capacity) {
 		std::lock_guard<std::mutex> g(db.pool.lock);
 		db.pool.CacheDrop(this);
@@ -332,7 +313,6 @@ void ColumnSegment::ScanRows(idx_t start_row, idx_t scan_count, data_ptr_t targe
 	if (scan_count == 0) return;
 	std::lock_guard<std::mutex> g(bit_compression_lock);
 	if (function->type == CompressionType::COMPRESSION_SUCCINCT && packed_on_device) {
-		SegmentDeviceRef ref = GetRef(this);
 		std::lock_guard<std::mutex> pg(db.pool.lock);
 		if (db.pool.cache_capacity) {
 			// vector-serving cache: decode the WHOLE segment once, serve this and the following vectors by memcpy
@@ -341,7 +321,7 @@ void ColumnSegment::ScanRows(idx_t start_row, idx_t scan_count, data_ptr_t targe
 				uint8_t *block = db.pool.CacheInsert(this, count * type_size);
 				if (block) {
 					void *d_all = db.pool.Staging(count * type_size);
-					Check(adac_unpack_range(ref.layout->layout, db.pool.d_arena, ref.index, 0, count, d_all, 0),
+					Check(adac_unpack_range(LayoutOf(device_layout), db.pool.d_arena, layout_index, 0, count, d_all, 0),
 					      "adac_unpack_range");
 					Check(adac_memcpy_d2h(db.pool.ctx, block, d_all, count * type_size), "adac_memcpy_d2h");
 					hit = block;
@@ -353,7 +333,7 @@ void ColumnSegment::ScanRows(idx_t start_row, idx_t scan_count, data_ptr_t targe
 			}
 		}
 		void *d_out = db.pool.Staging(scan_count * type_size);
-		Check(adac_unpack_range(ref.layout->layout, db.pool.d_arena, ref.index, start_row, scan_count, d_out, 0),
+		Check(adac_unpack_range(LayoutOf(device_layout), db.pool.d_arena, layout_index, start_row, scan_count, d_out, 0),
 		      "adac_unpack_range");
 		Check(adac_memcpy_d2h(db.pool.ctx, target, d_out, scan_count * type_size), "adac_memcpy_d2h");
 	} else {
@@ -511,7 +491,10 @@ void ColumnSegment::CompactMany(DatabaseInstance &db, const std::vector<ColumnSe
 		size_t p = 0;
 		for (size_t i = 0; i < segs.size(); i++) {
 			bool packed = p < pidx.size() && pidx[p] == i;
-			if (packed) SetRef(segs[i], SegmentDeviceRef {handle, p});
+			if (packed) {
+				segs[i]->device_layout = handle;
+				segs[i]->layout_index = p;
+			}
 			segs[i]->FinishCompaction(packed, widths[i], mm[2 * i], mm[2 * i + 1], rule,
 			                          packed ? descs[p].word_off : 0);
 			if (packed) p++;
@@ -555,18 +538,17 @@ void ColumnSegment::Uncompact() {
 	const idx_t compressed_size = adac_size_in_bytes(vec_slots, vec_width);
 	if (packed_on_device) {
 		raw.assign(segment_size, 0);
-		SegmentDeviceRef ref = GetRef(this);
 		std::lock_guard<std::mutex> pg(db.pool.lock);
 		if (count) {
 			void *d_out = db.pool.Staging(count * type_size);
-			Check(adac_unpack_range(ref.layout->layout, db.pool.d_arena, ref.index, 0, count, d_out, 0),
+			Check(adac_unpack_range(LayoutOf(device_layout), db.pool.d_arena, layout_index, 0, count, d_out, 0),
 			      "adac_unpack_range");
 			Check(adac_memcpy_d2h(db.pool.ctx, raw.data(), d_out, count * type_size), "adac_memcpy_d2h");
 		}
 		db.pool.Free(word_off, arena_words);
 		db.pool.CacheDrop(this);
 		packed_on_device = false;
-		DropRef(this);
+		device_layout.reset();
 	}
 	function = db.GetCompressionFunction(CompressionType::COMPRESSION_UNCOMPRESSED, type);
 	compacted = false;

@@ -270,6 +270,8 @@ private:
 	uint8_t vec_width = 64;
 	bool packed_on_device = false;
 	uint64_t word_off = 0, arena_words = 0;
+	std::shared_ptr<void> device_layout; // the batch adac_layout this segment was packed with (shared by the batch)
+	uint64_t layout_index = 0;           // this segment's index inside it
 	std::vector<uint8_t> raw;          // slots at 8*sizeof(T) bits / the uncompressed block
 	std::vector<uint64_t> validity;    // NULL rows of the append phase (consumed by the first compaction)
 	bool any_null = false;

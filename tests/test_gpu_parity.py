@@ -344,3 +344,27 @@ def test_argument_errors(adac, gpu_ctx):
     bad[0] = (8, 0, 0, 10, 5, 1, 0)  # word_off not a multiple of 16
     with pytest.raises(adac.AdacError):
         lay.set_descs(bad)
+
+
+def test_large_single_segments(adac, oracle, gpu_ctx):
+    """Segments far larger than DuckDB's 256 KiB blocks (the C ABI does not assume them): thousands of tiles per
+    segment, bit offsets beyond 2^31 inside one segment, every kernel."""
+    rng = np.random.default_rng(31)
+    for dtype, n, bits in ((np.uint32, 9_000_001, 21), (np.uint64, 5_000_003, 47), (np.uint8, 20_000_000, 5)):
+        dtype = np.dtype(dtype)
+        counts = np.array([n, 3, 70_000], dtype=np.uint32)
+        seg_vals = [make_values(rng, dtype, int(c), bits) for c in counts]
+        lay, d_words, _, descs, _ = run_encode_decode(adac, oracle, gpu_ctx, dtype, counts, seg_vals)
+        assert int(descs["width"][0]) == bits
+        d_res = gpu_ctx.alloc(len(counts) * 8)
+        lay.scan_sum(d_words, d_res)
+        udt = np.dtype("u%d" % dtype.itemsize)
+        assert d_res.download(np.uint64, 3).tolist() == \
+            [int(v.view(udt).astype(np.uint64).sum(dtype=np.uint64)) for v in seg_vals]
+        kv = seg_vals[0][n - 2]
+        lay.scan_count_eq(d_words, int(np.array([kv]).view(udt)[0]), d_res)
+        assert d_res.download(np.uint64, 3).tolist() == [int((v == kv).sum()) for v in seg_vals]
+        for start, cnt in ((n - 5000, 5000), (4_194_304 - 7, 100_000), (0, 1)):
+            d_out = gpu_ctx.alloc(cnt * dtype.itemsize + 64)
+            lay.unpack_range(d_words, 0, start, cnt, d_out, 1)
+            assert np.array_equal(d_out.download(dtype, cnt + 1)[1:], seg_vals[0][start:start + cnt])
