@@ -121,6 +121,7 @@ SIGNATURES = {
     "adac_fetch_rows": (_int, [_vp, _vp, _vp, _vp, _u64, _vp]),
     "adac_scan_sum": (_int, [_vp, _vp, _vp]),
     "adac_scan_count_eq": (_int, [_vp, _vp, _u64, _vp]),
+    "adac_scan_count_between": (_int, [_vp, _vp, _u64, _u64, _vp]),
 }
 
 
@@ -336,6 +337,11 @@ class Layout:
 
     def scan_sum(self, d_words, d_sums):
         _check(lib().adac_scan_sum(self._h, _dptr(d_words), _dptr(d_sums)), "adac_scan_sum")
+
+    def scan_count_between(self, d_words, lo, hi, d_counts):
+        """lo / hi: bit patterns of the column type (use int(np.array([v], dtype).view(unsigned)[0]) for signed)."""
+        _check(lib().adac_scan_count_between(self._h, _dptr(d_words), lo & NO_MIN, hi & NO_MIN, _dptr(d_counts)),
+               "adac_scan_count_between")
 
     def scan_count_eq(self, d_words, key, d_counts):
         _check(lib().adac_scan_count_eq(self._h, _dptr(d_words), key & NO_MIN, _dptr(d_counts)), "adac_scan_count_eq")

@@ -120,7 +120,6 @@ extern "C" int adac_set_tuning(const char *name, int value) {
 	if (!name) return 1;
 	const std::string n(name);
 	if (n == "persistent_unpack") adac::g_tuning.persistent_unpack = value;
-	else if (n == "persistent_scan") adac::g_tuning.persistent_scan = value;
 	else if (n == "scan_probe") adac::g_tuning.scan_probe = value;
 	else if (n == "templated_scan") adac::g_tuning.templated_scan = value;
 	else if (n == "scan_tiles_per_wg" && value > 0) adac::g_tuning.scan_tiles_per_wg = value;
@@ -450,12 +449,23 @@ extern "C" adac_status adac_scan_sum(adac_layout *l, const uint64_t *d_words, ui
 	return ADAC_OK;
 }
 
-extern "C" adac_status adac_scan_count_eq(adac_layout *l, const uint64_t *d_words, uint64_t key, uint64_t *d_counts) {
+extern "C" adac_status adac_scan_count_between(adac_layout *l, const uint64_t *d_words, uint64_t lo, uint64_t hi,
+                                               uint64_t *d_counts) {
 	if (!l || (l->nseg && !d_counts) || (l->total_values && !d_words)) return ADAC_ERR_INVALID_ARGUMENT;
 	if (!aligned16(d_words)) return ADAC_ERR_INVALID_ARGUMENT;
 	ADAC_HIP(hipSetDevice(l->ctx->device));
 	if (l->nseg) ADAC_HIP(hipMemsetAsync(d_counts, 0, l->nseg * sizeof(uint64_t), l->ctx->stream));
-	ADAC_HIP(adac::launch_scan_count_eq(l->ctx->stream, l->type_size, l->d_descs, l->d_tiles, l->ntiles, d_words, key,
-	                                    d_counts));
+	// order-preserving map of T onto unsigned numbers: flip the sign bit of the signed types
+	const uint32_t bits = 8 * l->type_size;
+	const uint64_t umask = bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);
+	const uint64_t sbit = l->is_signed ? (1ull << (bits - 1)) : 0ull;
+	const uint64_t blo = (lo & umask) ^ sbit, bhi = (hi & umask) ^ sbit;
+	if (bhi < blo) return ADAC_OK; // empty range: all counts stay zero
+	ADAC_HIP(adac::launch_scan_count_range(l->ctx->stream, l->type_size, l->d_descs, l->d_tiles, l->ntiles, d_words, blo,
+	                                       bhi - blo, sbit, d_counts));
 	return ADAC_OK;
+}
+
+extern "C" adac_status adac_scan_count_eq(adac_layout *l, const uint64_t *d_words, uint64_t key, uint64_t *d_counts) {
+	return adac_scan_count_between(l, d_words, key, key, d_counts);
 }

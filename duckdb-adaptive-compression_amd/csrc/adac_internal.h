@@ -31,7 +31,6 @@ struct RangeArgs {
 // workgroups are launched.  Defaults are the measured-best settings on MI355X.
 struct Tuning {
 	int persistent_unpack = 0;  // measured 5-15 % slower than one tile per workgroup (profiles/r01_ab_*.json)
-	int persistent_scan = 0;
 	int scan_probe = 0;         // diagnostic: fused-scan loop + loads only (no field walk)
 	int templated_scan = 1;     // width-templated register path of the fused scans for 4 <= w <= 32
 	int scan_tiles_per_wg = 16; // tile-table entries per fused-scan workgroup
@@ -62,8 +61,8 @@ hipError_t launch_fetch(hipStream_t s, uint32_t type_size, const adac_segment_de
                         const uint32_t *d_segs, const uint32_t *d_rows, uint64_t n, void *d_out);
 hipError_t launch_scan_sum(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs, const TileRef *d_tiles,
                            uint64_t ntiles, const uint64_t *d_words, uint64_t *d_sums);
-hipError_t launch_scan_count_eq(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs,
-                                const TileRef *d_tiles, uint64_t ntiles, const uint64_t *d_words, uint64_t key,
-                                uint64_t *d_counts);
+hipError_t launch_scan_count_range(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs,
+                                   const TileRef *d_tiles, uint64_t ntiles, const uint64_t *d_words, uint64_t blo,
+                                   uint64_t bspan, uint64_t sbit, uint64_t *d_counts);
 
 } // namespace adac

@@ -332,15 +332,51 @@ __device__ __forceinline__ uint32_t field_of(const uint32_t (&nrm)[5], int j) {
 // values T(field + min) as unsigned T.  For T = u64 that is linear (sum of fields + n*min, mod 2^64); for
 // narrower T the per-element truncation is kept.  Partial sums of a chunk stay in 32-bit registers whenever
 // MAXV fields of W bits cannot overflow them.
+// Range predicate lo <= v <= hi in T's own order (signed for the INT types), through the order-preserving map
+// B(v) = bits(v) ^ sbit:  B(v) - blo <= bspan as unsigned numbers.  `==`, `<`, `<=`, `>`, `>=`, BETWEEN are all
+// instances (column_segment.cpp:575-844 FilterSelection's comparison kinds).
+struct RangePred {
+	uint64_t blo, bspan, sbit;
+};
+// The same predicate moved into the packed-field domain of one segment: ((f ^ fxor) - flo) <= span.
+struct FieldRange {
+	uint32_t fxor, flo, span;
+	bool any;
+};
+
+template <typename U>
+__device__ __forceinline__ FieldRange field_range(const RangePred &p, const adac_segment_desc &d, uint32_t mask) {
+	FieldRange r {0u, 0u, 0u, false};
+	const bool linear = (d.flags & ADAC_SEG_PACKED) && d.min != ADAC_NO_MIN;
+	if (linear) {
+		// v = min + f without wrap in T's order, so B(v) = B(min) + f
+		const uint64_t bmin = (uint64_t)(U)d.min ^ p.sbit;
+		const uint64_t bhi = p.blo + p.bspan;
+		if (bhi < bmin) return r;
+		const uint64_t flo = p.blo > bmin ? p.blo - bmin : 0ull;
+		if (flo > (uint64_t)mask) return r;
+		const uint64_t fhi = bhi - bmin < (uint64_t)mask ? bhi - bmin : (uint64_t)mask;
+		r.flo = (uint32_t)flo;
+		r.span = (uint32_t)(fhi - flo);
+	} else {
+		// the stored bits are the value (unpacked slots, or a segment without a frame of reference)
+		r.fxor = (uint32_t)p.sbit;
+		r.flo = (uint32_t)p.blo;
+		r.span = (uint32_t)p.bspan;
+	}
+	r.any = true;
+	return r;
+}
+
 template <int W, typename U, int OP>
 struct ChunkAgg {
 	static constexpr int MAXV = (128 + W - 1) / W;
 	static constexpr bool kFields32 = ((uint64_t)MAXV << W) <= 0xffffffffull; // MAXV fields fit a u32 sum
 	uint32_t p32 = 0;
 	uint64_t p64 = 0;
-	__device__ __forceinline__ void add(uint32_t f, uint32_t add_lo, uint32_t key_field) {
+	__device__ __forceinline__ void add(uint32_t f, uint32_t add_lo, const FieldRange &fr) {
 		if (OP == 1) {
-			p32 += (f == key_field) ? 1u : 0u; // key_field = key - min, compared on the packed field
+			p32 += (((f ^ fr.fxor) - fr.flo) <= fr.span) ? 1u : 0u; // the predicate, on the packed field
 		} else if (sizeof(U) == 8) {
 			if (kFields32) p32 += f; else p64 += f;
 		} else if (sizeof(U) == 4) {
@@ -356,18 +392,20 @@ struct ChunkAgg {
 };
 
 template <int W, typename U, int OP>
-__device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint32_t r0, uint32_t r1, uint32_t count,
-                                           uint64_t add, U key, uint64_t &acc) {
+__device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint32_t r0, uint32_t r1,
+                                           const adac_segment_desc &d, const RangePred &pred, uint64_t &acc) {
 	constexpr int MAXV = (128 + W - 1) / W;
 	constexpr uint32_t mask = W >= 32 ? 0xffffffffu : ((1u << W) - 1u);
 	const uint32_t c0 = (uint32_t)(((uint64_t)r0 * W) >> 7);       // r0 is a multiple of 128 rows
 	const uint32_t c1 = (uint32_t)(((uint64_t)r1 * W + 127) >> 7);
-	const uint32_t clast = (uint32_t)(((uint64_t)count * W + 127) >> 7) - 1; // last chunk holding data bits
+	const uint32_t clast = (uint32_t)(((uint64_t)d.count * W + 127) >> 7) - 1; // last chunk holding data bits
+	const uint64_t add = effective_add(d);
 	const uint32_t add_lo = (uint32_t)add;
-	// T(field + min) == key  <=>  field == T(key - min), and a field never exceeds W bits
-	const U kf = (U)(key - (U)add);
-	if (OP == 1 && (uint64_t)kf > (uint64_t)mask) return;
-	const uint32_t key_field = (uint32_t)kf;
+	FieldRange fr {0u, 0u, 0u, true};
+	if (OP == 1) {
+		fr = field_range<U>(pred, d, mask);
+		if (!fr.any) return; // zonemap-style skip: no row of this segment can satisfy the predicate
+	}
 	// software pipeline: the next chunk's loads are issued (unconditionally, index clamped into the segment)
 	// before the current chunk is decoded, so a wave always has a load in flight
 	uint32_t L = c0 + threadIdx.x;
@@ -399,13 +437,13 @@ __device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint
 		if (starting <= lim) { // interior chunk: only the last slot may be absent
 			nv = starting;
 #pragma unroll
-			for (int j = 0; j < MAXV - 1; j++) agg.add(field_of<W>(nrm, j), add_lo, key_field);
-			if (128 % W == 0 || starting == (uint32_t)MAXV) agg.add(field_of<W>(nrm, MAXV - 1), add_lo, key_field);
+			for (int j = 0; j < MAXV - 1; j++) agg.add(field_of<W>(nrm, j), add_lo, fr);
+			if (128 % W == 0 || starting == (uint32_t)MAXV) agg.add(field_of<W>(nrm, MAXV - 1), add_lo, fr);
 		} else { // the run ends inside this chunk
 			nv = lim;
 #pragma unroll
 			for (int j = 0; j < MAXV; j++) {
-				if ((uint32_t)j < nv) agg.add(field_of<W>(nrm, j), add_lo, key_field);
+				if ((uint32_t)j < nv) agg.add(field_of<W>(nrm, j), add_lo, fr);
 			}
 		}
 		acc += agg.total(nv, add);
@@ -414,9 +452,10 @@ __device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint
 
 template <typename U, int OP>
 __device__ __forceinline__ void scan_run_dispatch(uint32_t w, const uint4 *__restrict__ seg16, uint32_t r0,
-                                                  uint32_t r1, uint32_t count, uint64_t add, U key, uint64_t &acc) {
+                                                  uint32_t r1, const adac_segment_desc &d, const RangePred &pred,
+                                                  uint64_t &acc) {
 	switch (w) {
-#define ADAC_W(N) case N: scan_run_w<N, U, OP>(seg16, r0, r1, count, add, key, acc); break;
+#define ADAC_W(N) case N: scan_run_w<N, U, OP>(seg16, r0, r1, d, pred, acc); break;
 		ADAC_W(4) ADAC_W(5) ADAC_W(6) ADAC_W(7) ADAC_W(8) ADAC_W(9) ADAC_W(10) ADAC_W(11) ADAC_W(12) ADAC_W(13)
 		ADAC_W(14) ADAC_W(15) ADAC_W(16) ADAC_W(17) ADAC_W(18) ADAC_W(19) ADAC_W(20) ADAC_W(21) ADAC_W(22)
 		ADAC_W(23) ADAC_W(24) ADAC_W(25) ADAC_W(26) ADAC_W(27) ADAC_W(28) ADAC_W(29) ADAC_W(30) ADAC_W(31) ADAC_W(32)
@@ -425,18 +464,17 @@ __device__ __forceinline__ void scan_run_dispatch(uint32_t w, const uint4 *__res
 	}
 }
 
-template <typename U, int OP> // OP 0: sum, 1: count == key
+template <typename U, int OP> // OP 0: SUM, 1: COUNT(lo <= v <= hi), 2: load-only probe
 __global__ __launch_bounds__(kWorkgroup) void k_scan_agg(const adac_segment_desc *__restrict__ descs,
                                                          const TileRef *__restrict__ tiles, uint32_t ntiles,
                                                          uint32_t group, int templated,
-                                                         const uint64_t *__restrict__ words, uint64_t key,
+                                                         const uint64_t *__restrict__ words, RangePred pred,
                                                          uint64_t *__restrict__ result) {
 	constexpr uint32_t TILE = kTileBytes / sizeof(U);
 	__shared__ uint4 lds[kTileBytes / 16 + 2];
 	const uint32_t *lds32 = reinterpret_cast<const uint32_t *>(lds);
 	uint32_t t = blockIdx.x * group;
 	const uint32_t hi = t + group < ntiles ? t + group : ntiles;
-	const U k = (U)key;
 	uint64_t acc = 0;
 	uint32_t seg = tiles[t].seg;
 	auto flush = [&](uint32_t to_seg) {
@@ -454,7 +492,9 @@ __global__ __launch_bounds__(kWorkgroup) void k_scan_agg(const adac_segment_desc
 		}
 		const adac_segment_desc d = descs[r.seg];
 		const uint32_t w = d.width;
-		if (templated && w >= 4 && w <= 32 && (uint64_t)d.count * w < (1ull << 31)) {
+		const bool linear = (d.flags & ADAC_SEG_PACKED) && d.min != ADAC_NO_MIN;
+		if (templated && w >= 4 && w <= 32 && (uint64_t)d.count * w < (1ull << 31) &&
+		    (OP != 1 || linear || sizeof(U) <= 4)) {
 			// width-templated register path: the whole run of this segment's tiles in this group, no LDS
 			// tiles of one segment are consecutive table entries, so the run length is arithmetic (walking the
 			// table entry by entry costs one dependent scalar load per tile: measured 3.0 -> TB/s-bound)
@@ -462,8 +502,8 @@ __global__ __launch_bounds__(kWorkgroup) void k_scan_agg(const adac_segment_desc
 			const uint32_t tiles_left = (left + TILE - 1) / TILE;
 			const uint32_t run = tiles_left < hi - t ? tiles_left : hi - t;
 			const uint32_t n = left < run * TILE ? left : run * TILE;
-			scan_run_dispatch<U, OP>(w, reinterpret_cast<const uint4 *>(words + d.word_off), r.first, r.first + n,
-			                         d.count, effective_add(d), k, acc);
+			scan_run_dispatch<U, OP>(w, reinterpret_cast<const uint4 *>(words + d.word_off), r.first, r.first + n, d,
+			                         pred, acc);
 			t += run;
 			continue;
 		}
@@ -481,7 +521,11 @@ __global__ __launch_bounds__(kWorkgroup) void k_scan_agg(const adac_segment_desc
 #pragma unroll
 			for (int j = 0; j < KK; j++) {
 				if (full || (uint32_t)(base + j) < n) {
-					acc += OP == 1 ? (uint64_t)(vals[j] == k) : (uint64_t)vals[j];
+					if (OP == 1) {
+						acc += (((uint64_t)vals[j] ^ pred.sbit) - pred.blo) <= pred.bspan ? 1ull : 0ull;
+					} else {
+						acc += (uint64_t)vals[j];
+					}
 				}
 			}
 		};
@@ -497,7 +541,7 @@ __global__ __launch_bounds__(kWorkgroup) void k_scan_agg(const adac_segment_desc
 }
 
 // ---------------------------------------------------------------------------------------------
-// Persistent forms of the two scan kernels.  A single tile's chain (tile table -> descriptor -> packed loads ->
+// Persistent form of the decode kernel (A/B option).  A single tile's chain (tile table -> descriptor -> packed loads ->
 // barrier -> decode [-> wave reduce -> atomic]) is serial and its fixed part is as long as the decode of a
 // 16 KiB tile, so read-only scans leave HBM idle.  Here a workgroup owns a CONTIGUOUS run of tiles and keeps
 // the next tile's packed bytes in flight with LDS-DMA (global_load_lds_dwordx4: global -> LDS, no VGPRs)
@@ -587,57 +631,6 @@ __global__ __launch_bounds__(kWorkgroup) void k_unpack_p(const adac_segment_desc
 		buf ^= 1;
 		t++;
 	}
-}
-
-template <typename U, int OP> // OP 0: sum, 1: count == key
-__global__ __launch_bounds__(kWorkgroup) void k_scan_agg_p(const adac_segment_desc *__restrict__ descs,
-                                                           const TileRef *__restrict__ tiles, uint32_t ntiles,
-                                                           const uint64_t *__restrict__ words, uint64_t key,
-                                                           uint64_t *__restrict__ result) {
-	constexpr int TILE = kTileBytes / (int)sizeof(U);
-	__shared__ uint4 lds[2][kMaxChunks];
-	uint32_t t, hi;
-	tile_range(ntiles, t, hi);
-	if (t >= hi) return;
-	TileJob cur = make_job<TILE>(descs, tiles, t, words);
-	dma_chunks(cur.src, cur.nchunks, lds[0]);
-	uint32_t buf = 0;
-	const U k = (U)key;
-	uint64_t acc = 0; // this lane's share of the current segment's aggregate
-	auto flush = [&](uint32_t seg) {
-		const uint64_t tot = wave_sum(acc);
-		if ((threadIdx.x & 63) == 0 && tot != 0) { // wrapping sums commute: one atomic per wave and segment run
-			atomicAdd(reinterpret_cast<unsigned long long *>(result + seg), (unsigned long long)tot);
-		}
-		acc = 0;
-	};
-	for (;;) {
-		__syncthreads();
-		const bool more = t + 1 < hi;
-		TileJob nxt = cur;
-		if (more) {
-			nxt = make_job<TILE>(descs, tiles, t + 1, words);
-			dma_chunks(nxt.src, nxt.nchunks, lds[buf ^ 1]);
-		}
-		const uint32_t *lds32 = reinterpret_cast<const uint32_t *>(lds[buf]);
-		const uint32_t n = cur.n;
-		auto sink = [&](int32_t base, const U *vals, bool full) {
-			constexpr int KK = 16 / (int)sizeof(U);
-#pragma unroll
-			for (int j = 0; j < KK; j++) {
-				if (full || (uint32_t)(base + j) < n) {
-					acc += OP == 0 ? (uint64_t)vals[j] : (uint64_t)(vals[j] == k);
-				}
-			}
-		};
-		decode_tile<U>(lds32, cur.bit0, cur.w, cur.add, n, 0u, sink);
-		if (!more) break;
-		if (nxt.seg != cur.seg) flush(cur.seg); // wave-uniform
-		cur = nxt;
-		buf ^= 1;
-		t++;
-	}
-	flush(cur.seg);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1015,37 +1008,29 @@ hipError_t launch_scan_sum(hipStream_t s, uint32_t type_size, const adac_segment
 	if (ntiles == 0) return hipSuccess;
 	return dispatch_size(type_size, [&](auto tag) {
 		using U = decltype(tag);
-		if (g_tuning.persistent_scan) {
-			hipLaunchKernelGGL((k_scan_agg_p<U, 0>), dim3(persistent_grid(ntiles)), dim3(kWorkgroup), 0, s, d_descs,
-			                   d_tiles, (uint32_t)ntiles, d_words, (uint64_t)0, d_sums);
-			return hipGetLastError();
-		}
 		const uint32_t per = (uint32_t)g_tuning.scan_tiles_per_wg;
+		const dim3 grid((unsigned)((ntiles + per - 1) / per));
 		if (g_tuning.scan_probe) { // diagnostic: the scan's loop and loads without the field walk (result meaningless)
-			hipLaunchKernelGGL((k_scan_agg<U, 2>), dim3((unsigned)((ntiles + per - 1) / per)), dim3(kWorkgroup), 0, s,
-			                   d_descs, d_tiles, (uint32_t)ntiles, per, 1, d_words, (uint64_t)0, d_sums);
+			hipLaunchKernelGGL((k_scan_agg<U, 2>), grid, dim3(kWorkgroup), 0, s, d_descs, d_tiles, (uint32_t)ntiles, per,
+			                   1, d_words, RangePred {}, d_sums);
 			return hipGetLastError();
 		}
-		hipLaunchKernelGGL((k_scan_agg<U, 0>), dim3((unsigned)((ntiles + per - 1) / per)), dim3(kWorkgroup), 0, s,
-		                   d_descs, d_tiles, (uint32_t)ntiles, per, g_tuning.templated_scan, d_words, (uint64_t)0, d_sums);
+		hipLaunchKernelGGL((k_scan_agg<U, 0>), grid, dim3(kWorkgroup), 0, s, d_descs, d_tiles, (uint32_t)ntiles, per,
+		                   g_tuning.templated_scan, d_words, RangePred {}, d_sums);
 		return hipGetLastError();
 	});
 }
 
-hipError_t launch_scan_count_eq(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs,
-                                const TileRef *d_tiles, uint64_t ntiles, const uint64_t *d_words, uint64_t key,
-                                uint64_t *d_counts) {
+hipError_t launch_scan_count_range(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs,
+                                   const TileRef *d_tiles, uint64_t ntiles, const uint64_t *d_words, uint64_t blo,
+                                   uint64_t bspan, uint64_t sbit, uint64_t *d_counts) {
 	if (ntiles == 0) return hipSuccess;
 	return dispatch_size(type_size, [&](auto tag) {
 		using U = decltype(tag);
-		if (g_tuning.persistent_scan) {
-			hipLaunchKernelGGL((k_scan_agg_p<U, 1>), dim3(persistent_grid(ntiles)), dim3(kWorkgroup), 0, s, d_descs,
-			                   d_tiles, (uint32_t)ntiles, d_words, key, d_counts);
-			return hipGetLastError();
-		}
 		const uint32_t per = (uint32_t)g_tuning.scan_tiles_per_wg;
 		hipLaunchKernelGGL((k_scan_agg<U, 1>), dim3((unsigned)((ntiles + per - 1) / per)), dim3(kWorkgroup), 0, s,
-		                   d_descs, d_tiles, (uint32_t)ntiles, per, g_tuning.templated_scan, d_words, key, d_counts);
+		                   d_descs, d_tiles, (uint32_t)ntiles, per, g_tuning.templated_scan, d_words,
+		                   RangePred {blo, bspan, sbit}, d_counts);
 		return hipGetLastError();
 	});
 }

@@ -209,6 +209,14 @@ adac_status adac_scan_sum(adac_layout *l, const uint64_t *d_words, uint64_t *d_s
  * benchmark/micro/succinct/zipf_distribution.cpp:40-48 without materialising the column. */
 adac_status adac_scan_count_eq(adac_layout *l, const uint64_t *d_words, uint64_t key, uint64_t *d_counts);
 
+/* Fused scan + range filter: d_counts[seg] = rows with lo <= value <= hi in T's own order (signed for the INT
+ * types); lo / hi are bit patterns of T, zero-extended.  With lo = T's minimum or hi = T's maximum this is
+ * `<=` / `>=`, with lo == hi it is `==`: the comparison kinds ColumnSegment::FilterSelection pushes down
+ * (src/storage/table/column_segment.cpp:575-844).  Evaluated on the packed fields (lo - min, hi - min); a
+ * segment whose [min, min + 2^w) cannot intersect the range is skipped without reading it (zonemap skip). */
+adac_status adac_scan_count_between(adac_layout *l, const uint64_t *d_words, uint64_t lo, uint64_t hi,
+                                    uint64_t *d_counts);
+
 #ifdef __cplusplus
 }
 #endif

@@ -368,3 +368,53 @@ def test_large_single_segments(adac, oracle, gpu_ctx):
             d_out = gpu_ctx.alloc(cnt * dtype.itemsize + 64)
             lay.unpack_range(d_words, 0, start, cnt, d_out, 1)
             assert np.array_equal(d_out.download(dtype, cnt + 1)[1:], seg_vals[0][start:start + cnt])
+
+
+def test_range_predicates_on_packed_columns(adac, oracle, gpu_ctx):
+    """adac_scan_count_between: lo <= v <= hi in the column type's own order (signed for INT types), evaluated
+    on packed fields; `==`, `<=`, `>=`, BETWEEN and empty ranges; packed, unpacked (mixed-sign) and constant
+    segments; both fused-scan forms."""
+    rng = np.random.default_rng(41)
+    for dtype in (np.int8, np.uint8, np.int16, np.uint16, np.int32, np.uint32, np.int64, np.uint64):
+        dtype = np.dtype(dtype)
+        info = np.iinfo(dtype)
+        udt = np.dtype("u%d" % dtype.itemsize)
+        tb = 8 * dtype.itemsize
+        span = min(tb - 1, 13)
+        n = 30000
+        base_pos = int(info.max // 2) - (1 << span)
+        segs = [
+            (base_pos + rng.integers(0, 1 << span, size=n)).astype(dtype),                       # packed, positive
+            rng.integers(0, 1 << min(tb - 2, 5), size=4500).astype(dtype),                       # packed, narrow
+            np.full(777, info.max // 3, dtype=dtype),                                            # constant
+        ]
+        if dtype.kind == "i":
+            segs.append((int(info.min) + rng.integers(0, 1 << span, size=n)).astype(dtype))      # packed, negative
+            segs.append(rng.integers(-50, 50, size=9000).astype(dtype))                          # mixed sign: unpacked
+        else:
+            segs.append(rng.integers(0, int(info.max), size=9000, dtype=np.uint64).astype(dtype))  # full range: unpacked
+        counts = np.array([len(v) for v in segs], dtype=np.uint32)
+        lay, d_words, _, descs, _ = run_encode_decode(adac, oracle, gpu_ctx, dtype, counts, segs)
+        assert not (descs["flags"][-1] & adac.SEG_PACKED)
+        d_res = gpu_ctx.alloc(len(counts) * 8)
+
+        def bits(v):
+            return int(np.array([v]).astype(dtype).view(udt)[0])
+
+        probes = [(int(info.min), int(info.max)), (int(segs[0][5]), int(segs[0][5])), (base_pos + 100, base_pos + 900),
+                  (int(info.min), base_pos + 4000), (base_pos + 4000, int(info.max)), (3, 17), (0, 0),
+                  (int(info.max // 3), int(info.max // 3)), (10, 5)]
+        if dtype.kind == "i":
+            probes += [(-10, 10), (int(info.min), -1), (int(info.min) + 50, int(info.min) + 5000), (-1, 0)]
+        clip = lambda x: min(max(x, int(info.min)), int(info.max))  # noqa: E731
+        probes = [(clip(lo), clip(hi)) for lo, hi in probes]
+        try:
+            for templated in (1, 0):
+                adac.set_tuning("templated_scan", templated)
+                for lo, hi in probes:
+                    lay.scan_count_between(d_words, bits(lo), bits(hi), d_res)
+                    got = d_res.download(np.uint64, len(counts)).tolist()
+                    exp = [int(((v >= lo) & (v <= hi)).sum()) for v in segs]
+                    assert got == exp, (dtype, templated, lo, hi)
+        finally:
+            adac.set_tuning("templated_scan", 1)

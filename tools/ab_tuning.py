@@ -22,7 +22,7 @@ def main():
     rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 7
     ctx = adac.Context(0)
     rng = np.random.default_rng(1)
-    base = {"persistent_unpack": 0, "persistent_scan": 0, "scan_probe": 0}
+    base = {"persistent_unpack": 0, "scan_probe": 0}
     variants = [
         ("lds x1", dict(base, templated_scan=0, scan_tiles_per_wg=1)),
         ("lds x8", dict(base, templated_scan=0, scan_tiles_per_wg=8)),
@@ -32,7 +32,7 @@ def main():
         ("templ x32", dict(base, templated_scan=1, scan_tiles_per_wg=32)),
         ("probe x8", dict(base, templated_scan=1, scan_tiles_per_wg=8, scan_probe=1)),
         ("probe x16", dict(base, templated_scan=1, scan_tiles_per_wg=16, scan_probe=1)),
-        ("persistent-dma-8/cu", {"persistent_unpack": 1, "persistent_scan": 1, "blocks_per_cu": 8, "templated_scan": 0}),
+        ("persistent-dma-8/cu", {"persistent_unpack": 1, "blocks_per_cu": 8, "templated_scan": 0}),
     ]
     out = {"rows": rows, "rounds": rounds, "cases": []}
     cases = ((np.uint64, 8), (np.uint64, 16), (np.uint64, 32), (np.uint64, 48), (np.uint32, 8), (np.uint32, 16),
