@@ -113,6 +113,7 @@ SIGNATURES = {
     "adac_layout_get_minmax": (_int, [_vp, _vp]),
     "adac_layout_device_descs": (_vp, [_vp]),
     "adac_analyze": (_int, [_vp, _vp, _vp, _int]),
+    "adac_zonemap": (_int, [_vp, _vp, _vp, _vp]),
     "adac_plan": (_int, [_vp, _int, _int]),
     "adac_pack": (_int, [_vp, _vp, _vp, _vp]),
     "adac_encode": (_int, [_vp, _vp, _vp, _int, _int, _vp]),
@@ -313,6 +314,13 @@ class Layout:
 
     def analyze(self, d_vals, d_validity=None, rule=RULE_APPEND):
         _check(lib().adac_analyze(self._h, _dptr(d_vals), _dptr(d_validity), rule), "adac_analyze")
+
+    def zonemap(self, d_vals, d_validity=None):
+        """Per-segment typed (min, max) over the valid rows, as arrays of the column dtype."""
+        zm = np.zeros((self.nseg, 2), dtype=np.uint64)
+        _check(lib().adac_zonemap(self._h, _dptr(d_vals), _dptr(d_validity), zm.ctypes.data), "adac_zonemap")
+        udt = np.dtype("u%d" % self.dtype.itemsize)
+        return zm.astype(udt).view(self.dtype)
 
     def plan(self, rule=RULE_APPEND, pad_to_byte=False):
         _check(lib().adac_plan(self._h, rule, int(pad_to_byte)), "adac_plan")

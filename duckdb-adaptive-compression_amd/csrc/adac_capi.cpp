@@ -384,6 +384,31 @@ extern "C" adac_status adac_analyze(adac_layout *l, const void *d_vals, const ui
 	return ADAC_OK;
 }
 
+extern "C" adac_status adac_zonemap(adac_layout *l, const void *d_vals, const uint64_t *d_validity, uint64_t *zonemap) {
+	if (!l || (!d_vals && l->total_values) || (l->nseg && !zonemap)) return ADAC_ERR_INVALID_ARGUMENT;
+	if (!aligned16(d_vals)) return ADAC_ERR_INVALID_ARGUMENT;
+	ADAC_HIP(hipSetDevice(l->ctx->device));
+	const uint32_t bits = 8 * l->type_size;
+	const uint64_t umask = bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);
+	const uint64_t sbit = l->is_signed ? (1ull << (bits - 1)) : 0ull;
+	ADAC_HIP(adac::launch_minmax_init(l->ctx->stream, l->d_minmax, l->nseg));
+	// the kernel's `null_bits` argument carries the sign bit: min/max are taken over bits(v) ^ signbit
+	ADAC_HIP(adac::launch_analyze(l->ctx->stream, l->type_size, false, sbit, ADAC_RULE_ZONEMAP, l->d_descs, l->d_tiles,
+	                              l->ntiles, d_vals, d_validity, l->d_minmax));
+	adac_status st = adac_layout_get_minmax(l, zonemap);
+	if (st != ADAC_OK) return st;
+	for (uint64_t s = 0; s < l->nseg; s++) {
+		uint64_t mn = zonemap[2 * s], mx = zonemap[2 * s + 1];
+		if (mn == UINT64_MAX && mx == 0) { // no valid row: empty interval
+			mn = umask;
+			mx = 0;
+		}
+		zonemap[2 * s] = (mn ^ sbit) & umask;
+		zonemap[2 * s + 1] = (mx ^ sbit) & umask;
+	}
+	return ADAC_OK;
+}
+
 extern "C" adac_status adac_plan(adac_layout *l, int rule, int pad_to_byte) {
 	if (!l || (rule != ADAC_RULE_APPEND && rule != ADAC_RULE_RECOMPACT)) return ADAC_ERR_INVALID_ARGUMENT;
 	ADAC_HIP(hipSetDevice(l->ctx->device));

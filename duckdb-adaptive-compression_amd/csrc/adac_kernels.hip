@@ -692,7 +692,8 @@ __global__ __launch_bounds__(kWorkgroup) void k_analyze(const adac_segment_desc 
 			__builtin_memcpy(v, &q[r], 16);
 #pragma unroll
 			for (int j = 0; j < K; j++) {
-				const uint64_t x = (rule == ADAC_RULE_APPEND && sign_extend) ? (uint64_t)(int64_t)(S)v[j] : (uint64_t)v[j];
+				const uint64_t x = rule == ADAC_RULE_ZONEMAP ? ((uint64_t)v[j] ^ null_bits)
+				                   : (rule == ADAC_RULE_APPEND && sign_extend) ? (uint64_t)(int64_t)(S)v[j] : (uint64_t)v[j];
 				mn = x < mn ? x : mn;
 				mx = x > mx ? x : mx;
 			}
@@ -708,7 +709,12 @@ __global__ __launch_bounds__(kWorkgroup) void k_analyze(const adac_segment_desc 
 			if ((uint32_t)(base + j) >= t.n) continue;
 			const bool valid = (vbits >> j) & 1u;
 			uint64_t x;
-			if (rule == ADAC_RULE_APPEND) {
+			if (rule == ADAC_RULE_ZONEMAP) {
+				// NumericStatistics::Update<T> (numeric_statistics.hpp:54-67): typed min/max over the valid rows,
+				// here in the order-preserving biased form bits(v) ^ signbit (null_bits IS the sign bit of T)
+				if (!valid) continue;
+				x = (uint64_t)v[j] ^ null_bits;
+			} else if (rule == ADAC_RULE_APPEND) {
 				// succinct.cpp:286-287: uint64_t(sdata[i]); NULL rows do not take part
 				if (!valid) continue;
 				x = sign_extend ? (uint64_t)(int64_t)(S)v[j] : (uint64_t)v[j];

@@ -54,7 +54,11 @@ typedef enum adac_rule {
 	/* BitCompressFromUncompressed (column_segment.cpp:385-456): min/max over the raw block zero-extended,
 	 * NULL slots (NullValue<T>) included; max reduced by min only when max > min, so a constant non-zero
 	 * segment keeps w = hi(value)+1. */
-	ADAC_RULE_RECOMPACT = 1
+	ADAC_RULE_RECOMPACT = 1,
+	/* Not an encode rule: typed min/max of the valid rows in T's own order — the segment zonemap
+	 * (NumericStatistics::Update<T>, src/include/duckdb/storage/statistics/numeric_statistics.hpp:54-67, read by
+	 * RowGroup::CheckZonemapSegments, src/storage/table/row_group.cpp:287-322).  adac_zonemap only. */
+	ADAC_RULE_ZONEMAP = 2
 } adac_rule;
 
 #define ADAC_NO_MIN UINT64_MAX /* ColumnSegment::min_factor initial value: no frame of reference */
@@ -169,6 +173,12 @@ const adac_segment_desc *adac_layout_device_descs(const adac_layout *l);
  * d_vals: raw values of type T at element offsets val_off.  d_validity: DuckDB validity mask over the same
  * element index space (bit e of word e/64 set = row valid) or NULL = all valid. */
 adac_status adac_analyze(adac_layout *l, const void *d_vals, const uint64_t *d_validity, int rule);
+
+/* Segment zonemaps: zonemap[2*s] / [2*s+1] = minimum / maximum of segment s over its valid rows, as bit patterns
+ * of T (zero-extended), ordered as T orders them (signed for the INT types).  A segment without a valid row
+ * reports min = T's maximum and max = T's minimum (an empty interval).  Overwrites the layout's min/max
+ * scratch (run it before or after an encode, not between adac_analyze and adac_plan).  Synchronises. */
+adac_status adac_zonemap(adac_layout *l, const void *d_vals, const uint64_t *d_validity, uint64_t *zonemap);
 
 /* From the min/max left by adac_analyze compute every segment's width, flags, stored min and arena offset
  * on the device (no host round trip).  Replaces the width decision of column_segment.cpp:351-363 /

@@ -418,3 +418,35 @@ def test_range_predicates_on_packed_columns(adac, oracle, gpu_ctx):
                     assert got == exp, (dtype, templated, lo, hi)
         finally:
             adac.set_tuning("templated_scan", 1)
+
+
+def test_zonemaps(adac, gpu_ctx):
+    """adac_zonemap: NumericStatistics-style typed min/max per segment over the valid rows (signed order for
+    the INT types), the statistic RowGroup::CheckZonemapSegments skips segments with."""
+    rng = np.random.default_rng(51)
+    for dtype in (np.int8, np.uint16, np.int32, np.uint32, np.int64, np.uint64):
+        dtype = np.dtype(dtype)
+        info = np.iinfo(dtype)
+        counts = np.array([5000, 1, 70000, 300, 64], dtype=np.uint32)
+        segs = [rng.integers(info.min, info.max, size=int(c), dtype=np.int64 if dtype.kind == "i" else np.uint64,
+                             endpoint=True).astype(dtype) for c in counts]
+        total = int(counts.sum())
+        valid = rng.random(total) > 0.25
+        valid[5001:75001][:10] = True
+        valid[75301:] = False           # last segment: no valid row
+        vmask = np.packbits(valid, bitorder="little")
+        vmask = np.concatenate([vmask, np.zeros((-len(vmask)) % 8 + 8, np.uint8)]).view(np.uint64)
+        lay = adac.Layout(gpu_ctx, dtype, counts)
+        d_vals = gpu_ctx.upload(np.concatenate(segs))
+        zm = lay.zonemap(d_vals)
+        for s, v in enumerate(segs):
+            assert (zm[s, 0], zm[s, 1]) == (v.min(), v.max()), (dtype, s)
+        zm = lay.zonemap(d_vals, gpu_ctx.upload(vmask))
+        off = 0
+        for s, v in enumerate(segs):
+            ok = valid[off:off + len(v)]
+            off += len(v)
+            if ok.any():
+                assert (zm[s, 0], zm[s, 1]) == (v[ok].min(), v[ok].max()), (dtype, s)
+            else:
+                assert zm[s, 0] == info.max and zm[s, 1] == info.min  # empty interval
