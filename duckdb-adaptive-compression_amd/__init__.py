@@ -85,6 +85,9 @@ SIGNATURES = {
     "adac_packed_words": (_u64, [_u64, _u8]),
     "adac_size_in_bytes": (_u64, [_u64, _u8]),
     "adac_arena_words": (_u64, [_u64, _u8]),
+    "adac_block_bytes": (_u64, [_u64, _u8]),
+    "adac_block_write": (_u64, [_vp, _int, _vp, _vp, _u64]),
+    "adac_block_read": (_int, [_vp, _u64, _vp, _P(_int), _vp, _u64]),
     "adac_tile_values": (_u32, [_int]),
     "adac_set_tuning": (_int, [C.c_char_p, _int]),
     "adac_ctx_create": (_int, [_int, _vp, _P(_vp)]),
@@ -175,6 +178,31 @@ def packed_words(count, w):
 
 def arena_words(count, w):
     return lib().adac_arena_words(count, w)
+
+
+def block_write(desc, dtype, words):
+    """Persistent block image (bytes) of one packed segment: sdsl::int_vector<0> serialisation + 16-byte trailer."""
+    d = np.zeros(1, dtype=SEGMENT_DESC_DTYPE)
+    d[0] = desc
+    words = np.ascontiguousarray(words, dtype=np.uint64)
+    n = lib().adac_block_bytes(int(d["count"][0]), int(d["width"][0]))
+    out = np.zeros(n, dtype=np.uint8)
+    got = lib().adac_block_write(d.ctypes.data, physical_type(dtype), words.ctypes.data, out.ctypes.data, n)
+    if got != n:
+        raise AdacError(1, "adac_block_write")
+    return out.tobytes()
+
+
+def block_read(block):
+    """-> (desc record, numpy dtype, packed words)"""
+    buf = np.frombuffer(block, dtype=np.uint8)
+    d = np.zeros(1, dtype=SEGMENT_DESC_DTYPE)
+    t = _int()
+    words = np.zeros(max(1, len(buf) // 8), dtype=np.uint64)
+    _check(lib().adac_block_read(buf.ctypes.data, len(buf), d.ctypes.data, C.byref(t), words.ctypes.data, len(words)),
+           "adac_block_read")
+    nw = lib().adac_packed_words(int(d["count"][0]), int(d["width"][0]))
+    return d[0], numpy_dtype(t.value), words[:nw]
 
 
 def set_tuning(name, value):

@@ -111,6 +111,59 @@ extern "C" uint64_t adac_arena_words(uint64_t count, uint8_t width) {
 	return (((count * width + 64) >> 6) + 15) & ~15ull;
 }
 
+extern "C" uint64_t adac_block_bytes(uint64_t count, uint8_t width) {
+	return adac_size_in_bytes(count, width) + ADAC_BLOCK_TRAILER_BYTES;
+}
+
+extern "C" uint64_t adac_block_write(const adac_segment_desc *d, int physical_type, const uint64_t *words, void *out,
+                                     uint64_t cap) {
+	if (!d || !out || d->width == 0 || d->width > 64 || !adac_type_is_supported(physical_type)) return 0;
+	const uint64_t nwords = adac_packed_words(d->count, d->width);
+	if (nwords && !words) return 0;
+	const uint64_t total = adac_block_bytes(d->count, d->width);
+	if (cap < total) return 0;
+	uint8_t *p = static_cast<uint8_t *>(out);
+	const uint64_t bit_size = (uint64_t)d->count * d->width;
+	std::memcpy(p, &bit_size, 8); // int_vector<0>::write_header: m_size, then m_width
+	p[8] = d->width;
+	if (nwords) std::memcpy(p + 9, words, nwords * 8); // write_data: capacity()/64 words
+	uint8_t *t = p + 9 + nwords * 8;
+	std::memset(t, 0, ADAC_BLOCK_TRAILER_BYTES);
+	std::memcpy(t, &d->min, 8);
+	t[8] = d->flags;
+	t[9] = (uint8_t)physical_type;
+	return total;
+}
+
+extern "C" adac_status adac_block_read(const void *block, uint64_t len, adac_segment_desc *d, int *physical_type,
+                                       uint64_t *words_out, uint64_t cap_words) {
+	if (!block || !d || len < 9 + ADAC_BLOCK_TRAILER_BYTES) return ADAC_ERR_INVALID_ARGUMENT;
+	const uint8_t *p = static_cast<const uint8_t *>(block);
+	uint64_t bit_size;
+	std::memcpy(&bit_size, p, 8);
+	const uint8_t width = p[8];
+	if (width == 0 || width > 64 || bit_size % width != 0) return ADAC_ERR_INVALID_ARGUMENT;
+	const uint64_t count = bit_size / width;
+	if (count > 0xffffffffull) return ADAC_ERR_INVALID_ARGUMENT;
+	const uint64_t nwords = (bit_size + 63) >> 6;
+	if (len != 9 + nwords * 8 + ADAC_BLOCK_TRAILER_BYTES) return ADAC_ERR_INVALID_ARGUMENT;
+	const uint8_t *t = p + 9 + nwords * 8;
+	const int type = t[9];
+	if (!adac_type_is_supported(type)) return ADAC_ERR_UNSUPPORTED_TYPE;
+	const uint32_t full_w = 8 * adac_type_size(type);
+	const uint8_t flags = t[8];
+	if (width > full_w || (!(flags & ADAC_SEG_PACKED) && width != full_w)) return ADAC_ERR_INVALID_ARGUMENT;
+	if (nwords > cap_words || (nwords && !words_out)) return ADAC_ERR_INVALID_ARGUMENT;
+	if (nwords) std::memcpy(words_out, p + 9, nwords * 8);
+	std::memset(d, 0, sizeof(*d));
+	std::memcpy(&d->min, t, 8);
+	d->count = (uint32_t)count;
+	d->width = width;
+	d->flags = flags;
+	if (physical_type) *physical_type = type;
+	return ADAC_OK;
+}
+
 extern "C" uint32_t adac_tile_values(int t) {
 	uint32_t ts = adac_type_size(t);
 	return ts ? adac::tile_values(ts) : 0;

@@ -105,6 +105,22 @@ uint64_t adac_size_in_bytes(uint64_t count, uint8_t width);
 /* words a segment occupies in the packed arena: the SDSL allocation ((bits+64)>>6 words,
  * memory_management.hpp:353) rounded up to 128 B */
 uint64_t adac_arena_words(uint64_t count, uint8_t width);
+/* Persistent block image of one packed segment (the reference never defined one: ConvertToPersistent is a
+ * no-op for SUCCINCT, src/storage/table/column_segment.cpp:531-533).  Layout, little-endian:
+ *   [0, 9 + 8*W)   the sdsl::int_vector<0> serialisation of the packed vector — uint64 bit_size, uint8 width,
+ *                  W = ceil(bit_size/64) words (int_vector.hpp:602-609,1546-1578): sdsl::load() reads it back
+ *   then 16 bytes  uint64 min_factor, uint8 flags (ADAC_SEG_*), uint8 physical type, 6 zero bytes
+ * adac_size_in_bytes(count, width) + 16 bytes in total.  Host memory only. */
+#define ADAC_BLOCK_TRAILER_BYTES 16
+uint64_t adac_block_bytes(uint64_t count, uint8_t width);
+/* words: the segment's ceil(count*width/64) packed words (host copy).  Returns bytes written, 0 if cap is short. */
+uint64_t adac_block_write(const adac_segment_desc *desc, int physical_type, const uint64_t *words, void *out,
+                          uint64_t cap);
+/* Parses a block: fills desc (count, width, min, flags; word_off/val_off left 0), *physical_type, and copies
+ * the packed words to words_out (capacity cap_words).  ADAC_ERR_INVALID_ARGUMENT on a malformed block. */
+adac_status adac_block_read(const void *block, uint64_t len, adac_segment_desc *desc, int *physical_type,
+                            uint64_t *words_out, uint64_t cap_words);
+
 /* values per device tile for a type (16 KiB of decoded output) */
 uint32_t adac_tile_values(int physical_type);
 /* Launch-shape knobs for in-process A/B measurement: "persistent_unpack", "persistent_scan" (0/1),

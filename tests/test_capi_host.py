@@ -114,3 +114,31 @@ def test_workload_generator(adac):
     assert float((s2 == 1).mean()) > 0.55  # 1/zeta(2) = 0.608
     small = wl.zipf_column(100000, np.uint8, domain=200, skew=0.5, seed=3)
     assert small.max() <= 200 and small.min() >= 1
+
+
+def test_persistent_block_image(adac, oracle, golden):
+    """adac_block_write/read: the sdsl::int_vector<0> serialisation (uint64 bit size, uint8 width, words —
+    int_vector.hpp:602-609,1546-1578) of the packed vector + a 16-byte trailer.  Checked on K1..K6: the sdsl part
+    is exactly size_in_bytes long and carries the known words."""
+    import struct
+    for k in golden["sdsl"]:
+        dtype = np.dtype(k["dtype"])
+        words = np.array([int(w, 16) for w in k["words"]], dtype=np.uint64)
+        n = len(k["values"])
+        desc = (0, 0, int(k["min"], 16), n, k["width"], adac.SEG_PACKED, 0)
+        blob = adac.block_write(desc, dtype, words)
+        assert len(blob) == k["size_in_bytes"] + 16
+        bit_size, width = struct.unpack_from("<QB", blob, 0)
+        assert (bit_size, width) == (k["bit_size"], k["width"])
+        assert np.array_equal(np.frombuffer(blob, dtype="<u8", count=len(words), offset=9), words)
+        d, dt, w2 = adac.block_read(blob)
+        assert dt == dtype and int(d["count"]) == n and int(d["width"]) == k["width"]
+        assert int(d["min"]) == int(k["min"], 16) and int(d["flags"]) == adac.SEG_PACKED
+        assert np.array_equal(w2, words)
+        # the decoded block equals the original values (through the oracle's reader)
+        assert oracle.unpack_flat(w2, 0, n, int(d["width"]), int(d["min"]), dtype).tolist() == k["values"]
+    # malformed blocks are rejected
+    good = adac.block_write((0, 0, 5, 100, 7, 1, 0), np.uint32, np.arange(11, dtype=np.uint64))
+    for bad in (good[:-1], good + b"\0", b"\0" * 8 + bytes([0]) + good[9:], good[:8] + bytes([40]) + good[9:]):
+        with pytest.raises(adac.AdacError):
+            adac.block_read(bad)
