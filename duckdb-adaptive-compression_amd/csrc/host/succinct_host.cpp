@@ -86,6 +86,7 @@ void SegmentPool::CacheDrop(const void *key) {
 
 SegmentPool::~SegmentPool() {
 	for (auto &e : cache) adac_host_free_pinned(ctx, e.second.data);
+	if (h_pinned) adac_host_free_pinned(ctx, h_pinned);
 	if (d_staging) adac_dev_free(ctx, d_staging);
 	if (d_staging2) adac_dev_free(ctx, d_staging2);
 	if (d_arena) adac_dev_free(ctx, d_arena);
@@ -135,6 +136,18 @@ static void *Grow(adac_ctx *ctx, void *&buf, size_t &have, size_t want) {
 		have = n;
 	}
 	return buf;
+}
+
+uint8_t *SegmentPool::PinnedStaging(size_t bytes) {
+	if (bytes > pinned_bytes) {
+		if (h_pinned) adac_host_free_pinned(ctx, h_pinned);
+		h_pinned = nullptr;
+		size_t n = std::max(bytes, pinned_bytes * 2);
+		n = (n + 4095) & ~size_t(4095);
+		Check(adac_host_alloc_pinned(ctx, n, &h_pinned), "adac_host_alloc_pinned(staging)");
+		pinned_bytes = n;
+	}
+	return static_cast<uint8_t *>(h_pinned);
 }
 
 void *SegmentPool::Staging(size_t bytes) {
@@ -423,12 +436,12 @@ void ColumnSegment::CompactMany(DatabaseInstance &db, const std::vector<ColumnSe
 			span += (segs[i]->count + per16 - 1) / per16 * per16; // keep every segment 16-byte aligned
 			any_null |= (rule == ADAC_RULE_APPEND && segs[i]->any_null);
 		}
-		std::vector<uint8_t> host(span * ts + 16, 0);
+		const size_t host_bytes = span * ts + 16;
 		std::vector<uint64_t> vmask;
 		if (any_null) vmask.assign(span / 64 + 2, ~0ull);
-		for (size_t i = 0; i < segs.size(); i++) {
-			std::memcpy(host.data() + offs[i] * ts, segs[i]->raw.data(), segs[i]->count * ts);
-			if (any_null && segs[i]->any_null) {
+		if (any_null) {
+			for (size_t i = 0; i < segs.size(); i++) {
+				if (!segs[i]->any_null) continue;
 				for (idx_t r = 0; r < segs[i]->count; r++) {
 					if (!((segs[i]->validity[r >> 6] >> (r & 63)) & 1)) {
 						uint64_t e = offs[i] + r;
@@ -445,8 +458,32 @@ void ColumnSegment::CompactMany(DatabaseInstance &db, const std::vector<ColumnSe
 		{ // device work under the pool lock; representation flips (bit_compression_lock) after it is released
 		std::lock_guard<std::mutex> pg(db.pool.lock);
 		adac_ctx *ctx = db.pool.ctx;
-		void *d_vals = db.pool.Staging(host.size());
-		Check(adac_memcpy_h2d(ctx, d_vals, host.data(), host.size()), "upload rows");
+		// gather the segments' rows into page-locked staging (a few host threads for big batches: the gather,
+		// not PCIe, bounds a re-compaction round) and upload them with one copy at PCIe rate
+		uint8_t *host = db.pool.PinnedStaging(host_bytes);
+		{
+			auto gather = [&](size_t lo, size_t hi) {
+				for (size_t i = lo; i < hi; i++) {
+					std::memcpy(host + offs[i] * ts, segs[i]->raw.data(), segs[i]->count * ts);
+					const size_t end = (offs[i] + segs[i]->count) * ts;
+					const size_t next = i + 1 < segs.size() ? offs[i + 1] * ts : host_bytes;
+					std::memset(host + end, 0, next - end); // alignment gap
+				}
+			};
+			size_t nthreads = host_bytes > (8u << 20) ? std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
+			nthreads = std::min(nthreads, segs.size());
+			if (nthreads <= 1) {
+				gather(0, segs.size());
+			} else {
+				std::vector<std::thread> th;
+				for (size_t k = 0; k < nthreads; k++) {
+					th.emplace_back(gather, segs.size() * k / nthreads, segs.size() * (k + 1) / nthreads);
+				}
+				for (auto &t : th) t.join();
+			}
+		}
+		void *d_vals = db.pool.Staging(host_bytes);
+		Check(adac_memcpy_h2d(ctx, d_vals, host, host_bytes), "upload rows");
 		uint64_t *d_valid = nullptr;
 		if (any_null) {
 			d_valid = static_cast<uint64_t *>(db.pool.Staging2(vmask.size() * 8));

@@ -121,6 +121,7 @@ public:
 	}
 	void *Staging(size_t bytes);   // device scratch, grown on demand
 	void *Staging2(size_t bytes);  // second device scratch (validity)
+	uint8_t *PinnedStaging(size_t bytes); // page-locked host staging for uploads, grown on demand
 	std::mutex lock;               // serialises device work of this pool (one stream)
 
 	// Decoded-segment cache (page-locked host blocks, LRU by bytes).  Guarded by `lock`.
@@ -142,6 +143,8 @@ private:
 	size_t staging_bytes = 0;
 	void *d_staging2 = nullptr;
 	size_t staging2_bytes = 0;
+	void *h_pinned = nullptr;
+	size_t pinned_bytes = 0;
 };
 
 struct AccessStatistics {
