@@ -223,17 +223,17 @@ def main():
 
     import torch
     adac = importlib.import_module(PKG)
-    if not os.path.exists(adac.LIB_PATH):
-        if rank == 0:
-            importlib.import_module("__graft_entry__").build()
-    wl = importlib.import_module(PKG + ".workload")
     if not torch.cuda.is_available():
         raise adac.AdacError(5, "bench.py needs an MI355X (no CPU fallback)")
     if args.single_device_rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     comm = sh.Comm(backend=args.backend, device=local_rank)
+    # the native libraries normally arrive prebuilt with the tree; if not, rank 0 builds and the rest wait
+    if rank == 0 and not (os.path.exists(adac.LIB_PATH) and os.path.exists(os.path.join(ROOT, PKG, "libadacworkload.so"))):
+        importlib.import_module("__graft_entry__").build()
     comm.barrier()
+    wl = importlib.import_module(PKG + ".workload")
     stream = torch.cuda.Stream(device=local_rank)
     ctx = adac.Context(local_rank, stream.cuda_stream)
 
