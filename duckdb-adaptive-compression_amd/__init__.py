@@ -126,6 +126,12 @@ SIGNATURES = {
     "adac_scan_sum": (_int, [_vp, _vp, _vp]),
     "adac_scan_count_eq": (_int, [_vp, _vp, _u64, _vp]),
     "adac_scan_count_between": (_int, [_vp, _vp, _u64, _u64, _vp]),
+    "adac_bp_layout_create": (_int, [_vp, _int, _vp, _vp, _vp, _u64, _P(_vp)]),
+    "adac_bp_layout_destroy": (None, [_vp]),
+    "adac_bp_layout_ngroups": (_u64, [_vp]),
+    "adac_bp_layout_total_values": (_u64, [_vp]),
+    "adac_bp_unpack": (_int, [_vp, _vp, _vp]),
+    "adac_bp_fetch_rows": (_int, [_vp, _vp, _vp, _vp, _u64, _vp]),
 }
 
 
@@ -381,6 +387,43 @@ class Layout:
 
     def scan_count_eq(self, d_words, key, d_counts):
         _check(lib().adac_scan_count_eq(self._h, _dptr(d_words), key & NO_MIN, _dptr(d_counts)), "adac_scan_count_eq")
+
+
+class BitpackingLayout:
+    """Segments of DuckDB's on-disk BITPACKING codec resident in one device buffer (adac_bp_layout)."""
+
+    def __init__(self, ctx, dtype, block_offs, counts, out_offs=None):
+        self.ctx = ctx
+        self.dtype = np.dtype(dtype)
+        self.block_offs = np.ascontiguousarray(block_offs, dtype=np.uint64)
+        self.counts = np.ascontiguousarray(counts, dtype=np.uint32)
+        oo = None if out_offs is None else np.ascontiguousarray(out_offs, dtype=np.uint64)
+        h = _vp()
+        _check(lib().adac_bp_layout_create(ctx._h, physical_type(dtype), self.block_offs.ctypes.data,
+                                           self.counts.ctypes.data, None if oo is None else oo.ctypes.data,
+                                           len(self.counts), C.byref(h)), "adac_bp_layout_create")
+        self._h = h.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().adac_bp_layout_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pragma: no cover
+            pass
+
+    ngroups = property(lambda s: lib().adac_bp_layout_ngroups(s._h))
+    total_values = property(lambda s: lib().adac_bp_layout_total_values(s._h))
+
+    def unpack(self, d_blocks, d_out):
+        _check(lib().adac_bp_unpack(self._h, _dptr(d_blocks), _dptr(d_out)), "adac_bp_unpack")
+
+    def fetch_rows(self, d_blocks, d_segs, d_rows, n, d_out):
+        _check(lib().adac_bp_fetch_rows(self._h, _dptr(d_blocks), _dptr(d_segs), _dptr(d_rows), n, _dptr(d_out)),
+               "adac_bp_fetch_rows")
 
 
 from .layout import appender_segment_counts, aligned_value_offsets  # noqa: E402,F401

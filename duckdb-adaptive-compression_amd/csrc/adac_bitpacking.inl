@@ -1,0 +1,218 @@
+// adac_bitpacking.inl — device decode of DuckDB's on-disk BITPACKING segments (the persistent
+// counterpart of the succinct codec).  Included into adac_kernels.hip (same translation unit: it reuses the
+// packed-field reader, the LDS staging and the aligned-store sink of the succinct kernels — a 32-value
+// fastpforlib algorithm group is the same contiguous little-endian bit stream as an sdsl::int_vector).
+//
+// Block layout decoded here (paths relative to the reference checkout):
+//   [0,8)        offset of the byte just past the FIRST group's metadata entry    bitpacking.cpp:496-509
+//   data         grows up from byte 8; per metadata group (2048 rows):            bitpacking.cpp:374-437
+//                  CONSTANT        T constant
+//                  CONSTANT_DELTA  T frame_of_reference, T_S delta
+//                  FOR             T frame_of_reference, T width, packed (v - for)
+//                  DELTA_FOR       T frame_of_reference, T width, T_S delta_offset, packed (delta - for)
+//   metadata     one uint32 per group, mode << 24 | data offset; group g's entry at [first - 4(g+1), first - 4g)
+// Decode semantics: BitpackingScanState::LoadNextGroup + BitpackingScanPartial (bitpacking.cpp:583-640,736-821).
+
+struct BpGroup {
+	uint64_t block_off; // byte offset of the segment's block in the blocks buffer (16-byte aligned)
+	uint64_t out_off;   // element offset of the group's first row in the output
+	uint32_t group;     // metadata group index inside the segment
+	uint32_t rows;      // rows in this group (2048 except the segment's last)
+};
+
+constexpr int kBpGroupRows = 2048; // BITPACKING_METADATA_GROUP_SIZE (bitpacking.cpp:19)
+enum : uint32_t { kBpConstant = 1, kBpConstantDelta = 2, kBpDeltaFor = 3, kBpFor = 4 }; // bitpacking.hpp:15-22
+
+// T value at an arbitrarily aligned address (group headers are only sizeof(T)-packed)
+template <typename U>
+__device__ __forceinline__ U load_unaligned(const uint8_t *p) {
+	uint64_t v = 0;
+#pragma unroll
+	for (int i = 0; i < (int)sizeof(U); i++) v |= (uint64_t)p[i] << (8 * i);
+	return (U)v;
+}
+
+struct BpHeader {
+	uint32_t mode, width;
+	uint64_t frame, extra;  // extra: CONSTANT_DELTA's delta / DELTA_FOR's delta_offset
+	const uint8_t *payload; // packed fields (FOR / DELTA_FOR)
+};
+
+template <typename U>
+__device__ __forceinline__ BpHeader bp_header(const uint8_t *blk, uint32_t group) {
+	BpHeader h;
+	const uint64_t first = *reinterpret_cast<const uint64_t *>(blk);
+	const uint32_t enc = *reinterpret_cast<const uint32_t *>(blk + first - 4ull * (group + 1));
+	h.mode = enc >> 24;
+	const uint8_t *p = blk + (enc & 0x00ffffffu);
+	h.frame = (uint64_t)load_unaligned<U>(p); // CONSTANT: the constant
+	h.width = 0;
+	h.extra = 0;
+	h.payload = p;
+	if (h.mode == kBpConstantDelta) {
+		h.extra = (uint64_t)load_unaligned<U>(p + sizeof(U));
+	} else if (h.mode == kBpFor || h.mode == kBpDeltaFor) {
+		h.width = (uint32_t)load_unaligned<U>(p + sizeof(U)) & 0xffu; // (bitpacking_width_t) *(T *)ptr
+		h.payload = p + 2 * sizeof(U);
+		if (h.mode == kBpDeltaFor) {
+			h.extra = (uint64_t)load_unaligned<U>(h.payload);
+			h.payload += sizeof(U);
+		}
+	}
+	return h;
+}
+
+// Coalesced copy of `n` rows from an LDS array to out[0..n), 16-byte stores aligned on the output address.
+template <typename U>
+__device__ __forceinline__ void store_rows_from_lds(const U *lds_vals, U *dst, uint32_t n) {
+	constexpr int K = 16 / (int)sizeof(U);
+	const uint32_t align = (uint32_t)((reinterpret_cast<uintptr_t>(dst) / sizeof(U)) & (K - 1));
+	for (uint32_t c = threadIdx.x; c * K < n + align; c += kWorkgroup) {
+		const int32_t base = (int32_t)(c * K) - (int32_t)align;
+		if (base >= 0 && (uint32_t)(base + K) <= n) {
+			U v[K];
+#pragma unroll
+			for (int j = 0; j < K; j++) v[j] = lds_vals[base + j];
+			uint4 q;
+			__builtin_memcpy(&q, v, 16);
+			*reinterpret_cast<uint4 *>(dst + base) = q;
+		} else {
+#pragma unroll
+			for (int j = 0; j < K; j++) {
+				if ((uint32_t)(base + j) < n) dst[base + j] = lds_vals[base + j];
+			}
+		}
+	}
+}
+
+template <typename U>
+__global__ __launch_bounds__(kWorkgroup) void k_bp_unpack(const BpGroup *__restrict__ groups,
+                                                          const uint8_t *__restrict__ blocks, U *__restrict__ out) {
+	__shared__ uint4 lds[kTileBytes / 16 + 2];
+	__shared__ __attribute__((aligned(16))) U vals[kBpGroupRows];
+	__shared__ U wave_tot[kWorkgroup / 64];
+	const BpGroup g = groups[blockIdx.x];
+	const uint8_t *blk = blocks + g.block_off;
+	const BpHeader h = bp_header<U>(blk, g.group);
+	U *dst = out + g.out_off;
+	const uint32_t n = g.rows;
+	constexpr uint32_t K = 16 / sizeof(U);
+	const uint32_t align = (uint32_t)(g.out_off & (K - 1));
+
+	if (h.mode == kBpConstant || h.mode == kBpConstantDelta || h.width == 0) {
+		// CONSTANT: fill; CONSTANT_DELTA: i*delta + for (bitpacking.cpp:759-780); width 0: every field is zero
+		const U fr = (U)h.frame;
+		const U step = h.mode == kBpConstantDelta ? (U)h.extra : (U)0;
+		if (h.mode == kBpDeltaFor) { // zero-width deltas: v[i] = delta_offset + (i+1)*for
+			for (uint32_t i = threadIdx.x; i < n; i += kWorkgroup) dst[i] = (U)((U)h.extra + (U)(i + 1) * fr);
+		} else {
+			for (uint32_t i = threadIdx.x; i < n; i += kWorkgroup) dst[i] = (U)((U)i * step + fr);
+		}
+		return;
+	}
+
+	// stage the packed payload: it starts at an arbitrary byte, so align down to 16 and carry the bit offset
+	const uintptr_t addr = reinterpret_cast<uintptr_t>(h.payload);
+	const uint4 *src = reinterpret_cast<const uint4 *>(addr & ~uintptr_t(15));
+	const uint32_t bit0 = (uint32_t)(addr & 15) * 8u;
+	const uint32_t w = h.width;
+	const uint32_t nchunks = (bit0 + n * w + 127u) >> 7;
+	for (uint32_t c = threadIdx.x; c < nchunks; c += kWorkgroup) lds[c] = src[c];
+	__syncthreads();
+	const uint32_t *lds32 = reinterpret_cast<const uint32_t *>(lds);
+
+	if (h.mode == kBpFor) {
+		StoreSink<U> sink {dst, n}; // value = field + frame_of_reference (ApplyFrameOfReference)
+		if (sizeof(U) == 8 && w > 32) {
+			decode_rows<U, true>(lds32, bit0, w, h.frame, n, align, sink);
+		} else {
+			decode_rows<U, false>(lds32, bit0, w, h.frame, n, align, sink);
+		}
+		return;
+	}
+
+	// DELTA_FOR: v[i] = delta_offset + sum_{j<=i} (field[j] + for), wrapping in T (bitpacking.cpp:810-813).
+	// fields + for -> LDS; each lane scans 8 consecutive rows, lanes and waves are chained by a shuffle scan.
+	auto to_lds = [&](int32_t base, const U *v, bool full) {
+		constexpr int KK = 16 / (int)sizeof(U);
+#pragma unroll
+		for (int j = 0; j < KK; j++) {
+			if (full || (uint32_t)(base + j) < n) vals[base + j] = v[j];
+		}
+	};
+	if (sizeof(U) == 8 && w > 32) {
+		decode_rows<U, true>(lds32, bit0, w, h.frame, n, 0u, to_lds);
+	} else {
+		decode_rows<U, false>(lds32, bit0, w, h.frame, n, 0u, to_lds);
+	}
+	__syncthreads();
+	constexpr int PER = kBpGroupRows / kWorkgroup; // 8 consecutive rows per lane
+	U loc[PER];
+	U run = 0;
+#pragma unroll
+	for (int k = 0; k < PER; k++) {
+		const uint32_t r = threadIdx.x * PER + k;
+		run = (U)(run + (r < n ? vals[r] : (U)0));
+		loc[k] = run;
+	}
+	U incl = run; // inclusive scan of the lane totals inside the wave
+	const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) {
+		const U up = (U)__shfl_up((unsigned long long)incl, off, 64);
+		if (lane >= (uint32_t)off) incl = (U)(incl + up);
+	}
+	if (lane == 63) wave_tot[threadIdx.x >> 6] = incl;
+	__syncthreads();
+	U carry = (U)h.extra; // delta_offset, then the totals of the waves before this one
+	for (uint32_t wv = 0; wv < (threadIdx.x >> 6); wv++) carry = (U)(carry + wave_tot[wv]);
+	carry = (U)(carry + (U)(incl - run));
+#pragma unroll
+	for (int k = 0; k < PER; k++) {
+		const uint32_t r = threadIdx.x * PER + k;
+		if (r < n) vals[r] = (U)(loc[k] + carry);
+	}
+	__syncthreads();
+	store_rows_from_lds<U>(vals, dst, n);
+}
+
+// Point fetch (BitpackingFetchRow, bitpacking.cpp:827-870): one lane per row; a DELTA_FOR row needs the prefix of
+// its group (the reference decodes it the same way through Skip).
+template <typename U>
+__global__ __launch_bounds__(kWorkgroup) void k_bp_fetch(const uint64_t *__restrict__ block_offs,
+                                                         const uint8_t *__restrict__ blocks,
+                                                         const uint32_t *__restrict__ segs,
+                                                         const uint32_t *__restrict__ rows, uint64_t n,
+                                                         U *__restrict__ out) {
+	const uint64_t k = (uint64_t)blockIdx.x * kWorkgroup + threadIdx.x;
+	if (k >= n) return;
+	const uint8_t *blk = blocks + block_offs[segs[k]];
+	const uint32_t row = rows[k];
+	const uint32_t r = row % kBpGroupRows;
+	const BpHeader h = bp_header<U>(blk, row / kBpGroupRows);
+	auto field = [&](uint32_t i) -> uint64_t {
+		if (h.width == 0) return 0ull;
+		const uint64_t bit = (uint64_t)i * h.width;
+		uint64_t v = 0;
+		const uint8_t *p = h.payload + (bit >> 3);
+		const uint32_t sh = (uint32_t)(bit & 7);
+		const uint32_t nbytes = (sh + h.width + 7) >> 3; // <= 9
+		for (uint32_t b = 0; b < nbytes && b < 8; b++) v |= (uint64_t)p[b] << (8 * b);
+		v >>= sh;
+		if (nbytes > 8) v |= (uint64_t)p[8] << (64 - sh);
+		return h.width >= 64 ? v : (v & ((1ull << h.width) - 1ull));
+	};
+	U res;
+	if (h.mode == kBpConstant) {
+		res = (U)h.frame;
+	} else if (h.mode == kBpConstantDelta) {
+		res = (U)((U)r * (U)h.extra + (U)h.frame);
+	} else if (h.mode == kBpFor) {
+		res = (U)(field(r) + h.frame);
+	} else {
+		U acc = (U)h.extra;
+		for (uint32_t i = 0; i <= r; i++) acc = (U)(acc + (U)(field(i) + h.frame));
+		res = acc;
+	}
+	out[k] = res;
+}

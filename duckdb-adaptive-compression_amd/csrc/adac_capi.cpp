@@ -547,3 +547,95 @@ extern "C" adac_status adac_scan_count_between(adac_layout *l, const uint64_t *d
 extern "C" adac_status adac_scan_count_eq(adac_layout *l, const uint64_t *d_words, uint64_t key, uint64_t *d_counts) {
 	return adac_scan_count_between(l, d_words, key, key, d_counts);
 }
+
+// ------------------------------------------------------------------------------------------------
+// DuckDB BITPACKING segments: the persistent counterpart (decode side)
+// ------------------------------------------------------------------------------------------------
+
+struct adac_bp_layout {
+	adac_ctx *ctx = nullptr;
+	uint32_t type_size = 0;
+	uint64_t nseg = 0, ngroups = 0, total_values = 0;
+	std::vector<uint32_t> counts;
+	void *d_groups = nullptr;
+	uint64_t *d_block_offs = nullptr;
+};
+
+extern "C" adac_status adac_bp_layout_create(adac_ctx *c, int physical_type, const uint64_t *block_offs,
+                                             const uint32_t *counts, const uint64_t *out_offs, uint64_t nseg,
+                                             adac_bp_layout **out) {
+	if (!c || !out || (nseg && (!block_offs || !counts))) return ADAC_ERR_INVALID_ARGUMENT;
+	*out = nullptr;
+	if (!adac_type_is_supported(physical_type)) return ADAC_ERR_UNSUPPORTED_TYPE;
+	adac_bp_layout *l = new (std::nothrow) adac_bp_layout();
+	if (!l) return ADAC_ERR_OUT_OF_MEMORY;
+	l->ctx = c;
+	l->type_size = adac_type_size(physical_type);
+	l->nseg = nseg;
+	l->counts.assign(counts, counts + nseg);
+	std::vector<adac::BpGroupHost> groups;
+	uint64_t run = 0;
+	for (uint64_t s = 0; s < nseg; s++) {
+		if (block_offs[s] & 15) {
+			delete l;
+			return ADAC_ERR_INVALID_ARGUMENT;
+		}
+		const uint64_t off = out_offs ? out_offs[s] : run;
+		for (uint64_t r = 0; r < counts[s]; r += 2048) {
+			const uint32_t rows = (uint32_t)(counts[s] - r < 2048 ? counts[s] - r : 2048);
+			groups.push_back(adac::BpGroupHost {block_offs[s], off + r, (uint32_t)(r / 2048), rows});
+		}
+		run = off + counts[s];
+		l->total_values += counts[s];
+	}
+	l->ngroups = groups.size();
+	if (l->ngroups >= 0x7fffffffull) {
+		delete l;
+		return ADAC_ERR_INVALID_ARGUMENT;
+	}
+	hipError_t e = hipSetDevice(c->device);
+	if (e == hipSuccess) e = hipMalloc(&l->d_groups, (l->ngroups ? l->ngroups : 1) * sizeof(adac::BpGroupHost));
+	if (e == hipSuccess) e = hipMalloc((void **)&l->d_block_offs, (nseg ? nseg : 1) * sizeof(uint64_t));
+	if (e == hipSuccess && l->ngroups)
+		e = hipMemcpyAsync(l->d_groups, groups.data(), l->ngroups * sizeof(adac::BpGroupHost), hipMemcpyHostToDevice,
+		                   c->stream);
+	if (e == hipSuccess && nseg)
+		e = hipMemcpyAsync(l->d_block_offs, block_offs, nseg * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	if (e != hipSuccess) {
+		adac_status st = fail_hip(e, "adac_bp_layout_create");
+		adac_bp_layout_destroy(l);
+		return st;
+	}
+	*out = l;
+	return ADAC_OK;
+}
+
+extern "C" void adac_bp_layout_destroy(adac_bp_layout *l) {
+	if (!l) return;
+	(void)hipSetDevice(l->ctx->device);
+	if (l->d_groups) (void)hipFree(l->d_groups);
+	if (l->d_block_offs) (void)hipFree(l->d_block_offs);
+	delete l;
+}
+
+extern "C" uint64_t adac_bp_layout_ngroups(const adac_bp_layout *l) { return l ? l->ngroups : 0; }
+extern "C" uint64_t adac_bp_layout_total_values(const adac_bp_layout *l) { return l ? l->total_values : 0; }
+
+extern "C" adac_status adac_bp_unpack(adac_bp_layout *l, const void *d_blocks, void *d_out) {
+	if (!l || ((!d_blocks || !d_out) && l->total_values)) return ADAC_ERR_INVALID_ARGUMENT;
+	if (!aligned16(d_blocks) || !aligned16(d_out)) return ADAC_ERR_INVALID_ARGUMENT;
+	ADAC_HIP(hipSetDevice(l->ctx->device));
+	ADAC_HIP(adac::launch_bp_unpack(l->ctx->stream, l->type_size, l->d_groups, l->ngroups, d_blocks, d_out));
+	return ADAC_OK;
+}
+
+extern "C" adac_status adac_bp_fetch_rows(adac_bp_layout *l, const void *d_blocks, const uint32_t *d_segs,
+                                          const uint32_t *d_rows, uint64_t n, void *d_out) {
+	if (!l) return ADAC_ERR_INVALID_ARGUMENT;
+	if (n == 0) return ADAC_OK;
+	if (!d_blocks || !d_segs || !d_rows || !d_out || !aligned16(d_blocks)) return ADAC_ERR_INVALID_ARGUMENT;
+	ADAC_HIP(hipSetDevice(l->ctx->device));
+	ADAC_HIP(adac::launch_bp_fetch(l->ctx->stream, l->type_size, l->d_block_offs, d_blocks, d_segs, d_rows, n, d_out));
+	return ADAC_OK;
+}

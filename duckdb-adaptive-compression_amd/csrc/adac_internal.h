@@ -65,4 +65,16 @@ hipError_t launch_scan_count_range(hipStream_t s, uint32_t type_size, const adac
                                    const TileRef *d_tiles, uint64_t ntiles, const uint64_t *d_words, uint64_t blo,
                                    uint64_t bspan, uint64_t sbit, uint64_t *d_counts);
 
+// DuckDB BITPACKING segments (adac_bitpacking.inl).  Host view of one metadata group; must match BpGroup.
+struct BpGroupHost {
+	uint64_t block_off;
+	uint64_t out_off;
+	uint32_t group;
+	uint32_t rows;
+};
+hipError_t launch_bp_unpack(hipStream_t s, uint32_t type_size, const void *d_groups, uint64_t ngroups,
+                            const void *d_blocks, void *d_out);
+hipError_t launch_bp_fetch(hipStream_t s, uint32_t type_size, const uint64_t *d_block_offs, const void *d_blocks,
+                           const uint32_t *d_segs, const uint32_t *d_rows, uint64_t n, void *d_out);
+
 } // namespace adac

@@ -921,6 +921,8 @@ hipError_t dispatch_size(uint32_t type_size, F &&f) {
 	}
 }
 
+#include "adac_bitpacking.inl"
+
 unsigned persistent_grid(uint64_t ntiles) {
 	const uint64_t cap = (uint64_t)g_tuning.num_cus * (uint64_t)g_tuning.blocks_per_cu;
 	return (unsigned)(ntiles < cap ? ntiles : cap);
@@ -1037,6 +1039,30 @@ hipError_t launch_scan_count_range(hipStream_t s, uint32_t type_size, const adac
 		hipLaunchKernelGGL((k_scan_agg<U, 1>), dim3((unsigned)((ntiles + per - 1) / per)), dim3(kWorkgroup), 0, s,
 		                   d_descs, d_tiles, (uint32_t)ntiles, per, g_tuning.templated_scan, d_words,
 		                   RangePred {blo, bspan, sbit}, d_counts);
+		return hipGetLastError();
+	});
+}
+
+hipError_t launch_bp_unpack(hipStream_t s, uint32_t type_size, const void *d_groups, uint64_t ngroups,
+                            const void *d_blocks, void *d_out) {
+	if (ngroups == 0) return hipSuccess;
+	return dispatch_size(type_size, [&](auto tag) {
+		using U = decltype(tag);
+		hipLaunchKernelGGL(k_bp_unpack<U>, dim3((unsigned)ngroups), dim3(kWorkgroup), 0, s,
+		                   static_cast<const BpGroup *>(d_groups), static_cast<const uint8_t *>(d_blocks),
+		                   static_cast<U *>(d_out));
+		return hipGetLastError();
+	});
+}
+
+hipError_t launch_bp_fetch(hipStream_t s, uint32_t type_size, const uint64_t *d_block_offs, const void *d_blocks,
+                           const uint32_t *d_segs, const uint32_t *d_rows, uint64_t n, void *d_out) {
+	if (n == 0) return hipSuccess;
+	return dispatch_size(type_size, [&](auto tag) {
+		using U = decltype(tag);
+		hipLaunchKernelGGL(k_bp_fetch<U>, dim3((unsigned)((n + kWorkgroup - 1) / kWorkgroup)), dim3(kWorkgroup), 0, s,
+		                   d_block_offs, static_cast<const uint8_t *>(d_blocks), d_segs, d_rows, n,
+		                   static_cast<U *>(d_out));
 		return hipGetLastError();
 	});
 }

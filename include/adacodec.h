@@ -243,6 +243,28 @@ adac_status adac_scan_count_eq(adac_layout *l, const uint64_t *d_words, uint64_t
 adac_status adac_scan_count_between(adac_layout *l, const uint64_t *d_words, uint64_t lo, uint64_t hi,
                                     uint64_t *d_counts);
 
+/* ---------------------------------------------------------------------------------------------
+ * DuckDB BITPACKING segments — the persistent counterpart of the succinct codec, decode side.
+ * A segment is the block image DuckDB's checkpoint writes (src/storage/compression/bitpacking.cpp:357-538):
+ * metadata groups of 2048 rows in CONSTANT / CONSTANT_DELTA / DELTA_FOR / FOR mode, packed with fastpforlib.
+ * Replaces BitpackingScanPartial / BitpackingScan (:736-826) and BitpackingFetchRow (:827-870).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct adac_bp_layout adac_bp_layout;
+
+/* block_offs[i]: byte offset (multiple of 16) of segment i's block inside the device buffer handed to the scan
+ * calls — blocks must be followed by at least 16 readable bytes (a whole Storage::BLOCK_SIZE image is);
+ * counts[i]: rows of segment i; out_offs[i]: element offset of its first row in the output, NULL = back to back. */
+adac_status adac_bp_layout_create(adac_ctx *ctx, int physical_type, const uint64_t *block_offs, const uint32_t *counts,
+                                  const uint64_t *out_offs, uint64_t nseg, adac_bp_layout **out);
+void adac_bp_layout_destroy(adac_bp_layout *l);
+uint64_t adac_bp_layout_ngroups(const adac_bp_layout *l);
+uint64_t adac_bp_layout_total_values(const adac_bp_layout *l);
+/* Full scan: every row of every segment to d_out (16-byte aligned), one workgroup per 2048-row metadata group. */
+adac_status adac_bp_unpack(adac_bp_layout *l, const void *d_blocks, void *d_out);
+/* d_out[k] = row d_rows[k] of segment d_segs[k] */
+adac_status adac_bp_fetch_rows(adac_bp_layout *l, const void *d_blocks, const uint32_t *d_segs, const uint32_t *d_rows,
+                               uint64_t n, void *d_out);
+
 #ifdef __cplusplus
 }
 #endif
