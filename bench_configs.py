@@ -90,13 +90,60 @@ def adaptive(host, wl, nseg=400, rows=32767, periods=4):
     return out
 
 
+def bitpacking_scan(adac, n=50_000_000):
+    """Full scan of on-disk BITPACKING segments: blocks written by the oracle's restatement of the
+    reference's compress (CPU, untimed), decoded on the device; rates from HIP events on the codec stream."""
+    from oracle import bitpacking as bp
+    ctx = adac.Context(0)
+    rng = np.random.default_rng(11)
+    out = {"rows": n, "cases": []}
+    cols = {
+        "for_u32_w20": (5_000_000 + rng.integers(0, 1 << 20, size=n)).astype(np.uint32),
+        "delta_for_i64_sorted": (10 ** 12 + np.cumsum(rng.integers(0, 1 << 9, size=n))).astype(np.int64),
+        "for_u64_w32": (rng.integers(0, 1 << 32, size=n, dtype=np.uint64) + np.uint64(1 << 40)).astype(np.uint64),
+    }
+    stride = 262144
+    for name, v in cols.items():
+        t0 = time.perf_counter()
+        comp = bp.Compressed(v)
+        t_cpu = time.perf_counter() - t0
+        nseg = comp.nseg
+        buf = np.zeros(nseg * stride + 64, dtype=np.uint8)
+        counts = np.zeros(nseg, dtype=np.uint32)
+        used = 0
+        for i in range(nseg):
+            buf[i * stride:i * stride + bp.BLOCK_SIZE] = comp.block(i)
+            counts[i] = comp.count(i)
+            used += comp.size(i)
+        d_blocks = ctx.upload(buf)
+        lay = adac.BitpackingLayout(ctx, v.dtype, np.arange(nseg, dtype=np.uint64) * stride, counts)
+        d_out = ctx.alloc(n * v.dtype.itemsize + 64)
+        lay.unpack(d_blocks, d_out)
+        ctx.sync()
+        assert np.array_equal(d_out.download(v.dtype, n), v)
+        ctx.timer_start()
+        reps = 20
+        for _ in range(reps):
+            lay.unpack(d_blocks, d_out)
+        ms = ctx.timer_stop() / reps
+        out["cases"].append({
+            "name": name, "dtype": str(v.dtype), "segments": nseg, "compressed_bytes": used,
+            "modes": comp.groups_by_mode(), "cpu_compress_values_per_s": n / t_cpu, "decode_ms": ms,
+            "decode_values_per_s": n / (ms * 1e-3),
+            "algorithmic_GBps": (used + n * v.dtype.itemsize) / (ms * 1e-3) / 1e9,
+        })
+        del lay, d_blocks, d_out, comp
+    ctx.close()
+    return out
+
+
 def main():
     adac = importlib.import_module(PKG)
     adac.build()
     host = importlib.import_module(PKG + ".host")
     lay = importlib.import_module(PKG + ".layout")
     wl = importlib.import_module(PKG + ".workload")
-    res = {"plugin_scan": plugin_scan(host, lay), "adaptive": adaptive(host, wl)}
+    res = {"plugin_scan": plugin_scan(host, lay), "adaptive": adaptive(host, wl), "bitpacking_scan": bitpacking_scan(adac)}
     print(json.dumps(res))
 
 

@@ -130,6 +130,7 @@ SIGNATURES = {
     "adac_bp_layout_destroy": (None, [_vp]),
     "adac_bp_layout_ngroups": (_u64, [_vp]),
     "adac_bp_layout_total_values": (_u64, [_vp]),
+    "adac_bp_bind": (_int, [_vp, _vp]),
     "adac_bp_unpack": (_int, [_vp, _vp, _vp]),
     "adac_bp_fetch_rows": (_int, [_vp, _vp, _vp, _vp, _u64, _vp]),
 }
@@ -417,6 +418,9 @@ class BitpackingLayout:
 
     ngroups = property(lambda s: lib().adac_bp_layout_ngroups(s._h))
     total_values = property(lambda s: lib().adac_bp_layout_total_values(s._h))
+
+    def bind(self, d_blocks):
+        _check(lib().adac_bp_bind(self._h, _dptr(d_blocks)), "adac_bp_bind")
 
     def unpack(self, d_blocks, d_out):
         _check(lib().adac_bp_unpack(self._h, _dptr(d_blocks), _dptr(d_out)), "adac_bp_unpack")

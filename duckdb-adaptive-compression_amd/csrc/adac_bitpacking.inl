@@ -18,6 +18,11 @@ struct BpGroup {
 	uint64_t out_off;   // element offset of the group's first row in the output
 	uint32_t group;     // metadata group index inside the segment
 	uint32_t rows;      // rows in this group (2048 except the segment's last)
+	// filled by k_bp_prepare from the block image (adac_bp_bind): the group's parsed header, so the scan kernel
+	// starts its payload loads after ONE descriptor load instead of a chain of four dependent ones
+	uint64_t payload_off; // byte offset of the packed fields in the blocks buffer
+	uint64_t frame, extra;
+	uint32_t mode, width;
 };
 
 constexpr int kBpGroupRows = 2048; // BITPACKING_METADATA_GROUP_SIZE (bitpacking.cpp:19)
@@ -62,6 +67,20 @@ __device__ __forceinline__ BpHeader bp_header(const uint8_t *blk, uint32_t group
 	return h;
 }
 
+template <typename U>
+__global__ void k_bp_prepare(BpGroup *__restrict__ groups, uint64_t ngroups, const uint8_t *__restrict__ blocks) {
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= ngroups) return;
+	BpGroup g = groups[i];
+	const BpHeader h = bp_header<U>(blocks + g.block_off, g.group);
+	g.payload_off = (uint64_t)(h.payload - blocks);
+	g.frame = h.frame;
+	g.extra = h.extra;
+	g.mode = h.mode;
+	g.width = h.width;
+	groups[i] = g;
+}
+
 // Coalesced copy of `n` rows from an LDS array to out[0..n), 16-byte stores aligned on the output address.
 template <typename U>
 __device__ __forceinline__ void store_rows_from_lds(const U *lds_vals, U *dst, uint32_t n) {
@@ -92,8 +111,12 @@ __global__ __launch_bounds__(kWorkgroup) void k_bp_unpack(const BpGroup *__restr
 	__shared__ __attribute__((aligned(16))) U vals[kBpGroupRows];
 	__shared__ U wave_tot[kWorkgroup / 64];
 	const BpGroup g = groups[blockIdx.x];
-	const uint8_t *blk = blocks + g.block_off;
-	const BpHeader h = bp_header<U>(blk, g.group);
+	BpHeader h;
+	h.mode = g.mode;
+	h.width = g.width;
+	h.frame = g.frame;
+	h.extra = g.extra;
+	h.payload = blocks + g.payload_off;
 	U *dst = out + g.out_off;
 	const uint32_t n = g.rows;
 	constexpr uint32_t K = 16 / sizeof(U);

@@ -559,6 +559,7 @@ struct adac_bp_layout {
 	std::vector<uint32_t> counts;
 	void *d_groups = nullptr;
 	uint64_t *d_block_offs = nullptr;
+	const void *bound_blocks = nullptr; // blocks buffer whose group headers are parsed into d_groups
 };
 
 extern "C" adac_status adac_bp_layout_create(adac_ctx *c, int physical_type, const uint64_t *block_offs,
@@ -583,7 +584,7 @@ extern "C" adac_status adac_bp_layout_create(adac_ctx *c, int physical_type, con
 		const uint64_t off = out_offs ? out_offs[s] : run;
 		for (uint64_t r = 0; r < counts[s]; r += 2048) {
 			const uint32_t rows = (uint32_t)(counts[s] - r < 2048 ? counts[s] - r : 2048);
-			groups.push_back(adac::BpGroupHost {block_offs[s], off + r, (uint32_t)(r / 2048), rows});
+			groups.push_back(adac::BpGroupHost {block_offs[s], off + r, (uint32_t)(r / 2048), rows, 0, 0, 0, 0, 0});
 		}
 		run = off + counts[s];
 		l->total_values += counts[s];
@@ -622,9 +623,21 @@ extern "C" void adac_bp_layout_destroy(adac_bp_layout *l) {
 extern "C" uint64_t adac_bp_layout_ngroups(const adac_bp_layout *l) { return l ? l->ngroups : 0; }
 extern "C" uint64_t adac_bp_layout_total_values(const adac_bp_layout *l) { return l ? l->total_values : 0; }
 
+extern "C" adac_status adac_bp_bind(adac_bp_layout *l, const void *d_blocks) {
+	if (!l || (!d_blocks && l->total_values) || !aligned16(d_blocks)) return ADAC_ERR_INVALID_ARGUMENT;
+	ADAC_HIP(hipSetDevice(l->ctx->device));
+	ADAC_HIP(adac::launch_bp_prepare(l->ctx->stream, l->type_size, l->d_groups, l->ngroups, d_blocks));
+	l->bound_blocks = d_blocks;
+	return ADAC_OK;
+}
+
 extern "C" adac_status adac_bp_unpack(adac_bp_layout *l, const void *d_blocks, void *d_out) {
 	if (!l || ((!d_blocks || !d_out) && l->total_values)) return ADAC_ERR_INVALID_ARGUMENT;
 	if (!aligned16(d_blocks) || !aligned16(d_out)) return ADAC_ERR_INVALID_ARGUMENT;
+	if (l->bound_blocks != d_blocks) {
+		adac_status st = adac_bp_bind(l, d_blocks);
+		if (st != ADAC_OK) return st;
+	}
 	ADAC_HIP(hipSetDevice(l->ctx->device));
 	ADAC_HIP(adac::launch_bp_unpack(l->ctx->stream, l->type_size, l->d_groups, l->ngroups, d_blocks, d_out));
 	return ADAC_OK;

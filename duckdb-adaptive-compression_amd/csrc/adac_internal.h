@@ -71,7 +71,10 @@ struct BpGroupHost {
 	uint64_t out_off;
 	uint32_t group;
 	uint32_t rows;
+	uint64_t payload_off, frame, extra; // parsed header, filled on the device by launch_bp_prepare
+	uint32_t mode, width;
 };
+hipError_t launch_bp_prepare(hipStream_t s, uint32_t type_size, void *d_groups, uint64_t ngroups, const void *d_blocks);
 hipError_t launch_bp_unpack(hipStream_t s, uint32_t type_size, const void *d_groups, uint64_t ngroups,
                             const void *d_blocks, void *d_out);
 hipError_t launch_bp_fetch(hipStream_t s, uint32_t type_size, const uint64_t *d_block_offs, const void *d_blocks,

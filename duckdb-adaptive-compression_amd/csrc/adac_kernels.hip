@@ -1043,6 +1043,16 @@ hipError_t launch_scan_count_range(hipStream_t s, uint32_t type_size, const adac
 	});
 }
 
+hipError_t launch_bp_prepare(hipStream_t s, uint32_t type_size, void *d_groups, uint64_t ngroups, const void *d_blocks) {
+	if (ngroups == 0) return hipSuccess;
+	return dispatch_size(type_size, [&](auto tag) {
+		using U = decltype(tag);
+		hipLaunchKernelGGL(k_bp_prepare<U>, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, s,
+		                   static_cast<BpGroup *>(d_groups), ngroups, static_cast<const uint8_t *>(d_blocks));
+		return hipGetLastError();
+	});
+}
+
 hipError_t launch_bp_unpack(hipStream_t s, uint32_t type_size, const void *d_groups, uint64_t ngroups,
                             const void *d_blocks, void *d_out) {
 	if (ngroups == 0) return hipSuccess;

@@ -259,6 +259,11 @@ adac_status adac_bp_layout_create(adac_ctx *ctx, int physical_type, const uint64
 void adac_bp_layout_destroy(adac_bp_layout *l);
 uint64_t adac_bp_layout_ngroups(const adac_bp_layout *l);
 uint64_t adac_bp_layout_total_values(const adac_bp_layout *l);
+/* Parse every group's header (mode, width, frame of reference, payload position) out of the block images into
+ * the layout's device table — the analogue of BitpackingScanState::LoadNextGroup (bitpacking.cpp:597-640) for all
+ * groups at once.  adac_bp_unpack binds by itself when handed a different buffer; call this again after
+ * rewriting blocks in place. */
+adac_status adac_bp_bind(adac_bp_layout *l, const void *d_blocks);
 /* Full scan: every row of every segment to d_out (16-byte aligned), one workgroup per 2048-row metadata group. */
 adac_status adac_bp_unpack(adac_bp_layout *l, const void *d_blocks, void *d_out);
 /* d_out[k] = row d_rows[k] of segment d_segs[k] */
