@@ -133,6 +133,13 @@ SIGNATURES = {
     "adac_bp_bind": (_int, [_vp, _vp]),
     "adac_bp_unpack": (_int, [_vp, _vp, _vp]),
     "adac_bp_fetch_rows": (_int, [_vp, _vp, _vp, _vp, _u64, _vp]),
+    "adac_bp_plan_create": (_int, [_vp, _int, _vp, _vp, _u64, _int, _P(_vp)]),
+    "adac_bp_plan_destroy": (None, [_vp]),
+    "adac_bp_plan_encodable": (_int, [_vp]),
+    "adac_bp_plan_nseg": (_u64, [_vp]),
+    "adac_bp_plan_groups_by_mode": (_u64, [_vp, _int]),
+    "adac_bp_plan_segment": (_int, [_vp, _u64, _P(_u64), _P(_u64), _P(_u64)]),
+    "adac_bp_write": (_int, [_vp, _vp, _vp, _vp, _u64]),
 }
 
 
@@ -428,6 +435,48 @@ class BitpackingLayout:
     def fetch_rows(self, d_blocks, d_segs, d_rows, n, d_out):
         _check(lib().adac_bp_fetch_rows(self._h, _dptr(d_blocks), _dptr(d_segs), _dptr(d_rows), n, _dptr(d_out)),
                "adac_bp_fetch_rows")
+
+
+class BitpackingPlan:
+    """Compress side of the BITPACKING codec: device statistics + host mode decisions and block placement."""
+
+    BLOCK_STRIDE = 262144
+
+    def __init__(self, ctx, dtype, d_vals, n, d_validity=None, force_mode=0):
+        self.ctx = ctx
+        self.dtype = np.dtype(dtype)
+        self.n = n
+        h = _vp()
+        _check(lib().adac_bp_plan_create(ctx._h, physical_type(dtype), _dptr(d_vals), _dptr(d_validity), n, force_mode,
+                                         C.byref(h)), "adac_bp_plan_create")
+        self._h = h.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().adac_bp_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pragma: no cover
+            pass
+
+    encodable = property(lambda s: bool(lib().adac_bp_plan_encodable(s._h)))
+    nseg = property(lambda s: lib().adac_bp_plan_nseg(s._h))
+
+    def groups_by_mode(self):
+        return {name: lib().adac_bp_plan_groups_by_mode(self._h, m)
+                for m, name in ((1, "constant"), (2, "constant_delta"), (3, "delta_for"), (4, "for"))}
+
+    def segment(self, i):
+        a, b, c = _u64(), _u64(), _u64()
+        _check(lib().adac_bp_plan_segment(self._h, i, C.byref(a), C.byref(b), C.byref(c)), "adac_bp_plan_segment")
+        return a.value, b.value, c.value
+
+    def write(self, d_vals, d_blocks, d_validity=None, block_stride=None):
+        _check(lib().adac_bp_write(self._h, _dptr(d_vals), _dptr(d_validity), _dptr(d_blocks),
+                                   block_stride or self.BLOCK_STRIDE), "adac_bp_write")
 
 
 from .layout import appender_segment_counts, aligned_value_offsets  # noqa: E402,F401

@@ -239,3 +239,184 @@ __global__ __launch_bounds__(kWorkgroup) void k_bp_fetch(const uint64_t *__restr
 	}
 	out[k] = res;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Compress side.  The device produces per-group statistics and writes the group images; the mode decision and
+// the sequential placement of groups into 256 KiB blocks (BitpackingState::Flush, ReserveSpace/FlushSegment:
+// bitpacking.cpp:229-294,453-512) stay on the host — they are a few dozen scalar operations per 2048 rows.
+// NULL rows: the reference leaves whatever its compression buffer held (indeterminate); here a NULL row
+// contributes the value 0, i.e. the field (0 - frame_of_reference) mod 2^width.
+// ---------------------------------------------------------------------------------------------
+struct BpStats {
+	uint64_t bmin, bmax;   // min / max of the valid rows in T's order, as bits ^ signbit(T); bmin > bmax if none valid
+	uint64_t bdmin, bdmax; // min / max of d[i] = v[i] - v[i-1] (i >= 1) in T_S order, as bits ^ signbit(T_S)
+	uint64_t v0;           // bits of the first row
+	uint32_t rows, nvalid;
+	uint32_t delta_overflow; // some v[i] - v[i-1] (v[-1] = 0) is not representable in T_S
+	uint32_t pad;
+};
+
+template <typename U>
+__global__ __launch_bounds__(kWorkgroup) void k_bp_stats(const U *__restrict__ vals,
+                                                         const uint64_t *__restrict__ validity, uint64_t n,
+                                                         uint64_t sbit_t, BpStats *__restrict__ stats) {
+	using S = typename std::make_signed<U>::type;
+	constexpr int PER = kBpGroupRows / kWorkgroup;
+	constexpr uint64_t sbit_s = 1ull << (8 * sizeof(U) - 1);
+	__shared__ uint64_t red[6][kWorkgroup / 64];
+	const uint64_t g0 = (uint64_t)blockIdx.x * kBpGroupRows;
+	const uint32_t rows = (uint32_t)(n - g0 < (uint64_t)kBpGroupRows ? n - g0 : (uint64_t)kBpGroupRows);
+	uint64_t bmin = ~0ull, bmax = 0, bdmin = ~0ull, bdmax = 0, ovf = 0, nvalid = 0;
+	const uint32_t r0 = threadIdx.x * PER;
+	U prev = 0;
+	if (r0 > 0 && r0 - 1 < rows) prev = vals[g0 + r0 - 1];
+#pragma unroll
+	for (int k = 0; k < PER; k++) {
+		const uint32_t r = r0 + k;
+		if (r >= rows) break;
+		const U v = vals[g0 + r];
+		const uint64_t e = g0 + r;
+		const bool valid = validity == nullptr || ((validity[e >> 6] >> (e & 63)) & 1ull);
+		if (valid) {
+			const uint64_t b = (uint64_t)v ^ sbit_t;
+			bmin = b < bmin ? b : bmin;
+			bmax = b > bmax ? b : bmax;
+			nvalid++;
+		}
+		// (T_S)v[i] - (T_S)v[i-1] with the TrySubtractOperator overflow rule
+		S d;
+		const bool o = __builtin_sub_overflow((S)v, (S)prev, &d);
+		ovf |= o ? 1ull : 0ull;
+		if (r >= 1) {
+			const uint64_t bd = ((uint64_t)(U)d) ^ sbit_s;
+			bdmin = bd < bdmin ? bd : bdmin;
+			bdmax = bd > bdmax ? bd : bdmax;
+		}
+		prev = v;
+	}
+	bmin = wave_min(bmin);
+	bmax = wave_max(bmax);
+	bdmin = wave_min(bdmin);
+	bdmax = wave_max(bdmax);
+	ovf = wave_max(ovf);
+	nvalid = wave_sum(nvalid);
+	if ((threadIdx.x & 63) == 0) {
+		const uint32_t wv = threadIdx.x >> 6;
+		red[0][wv] = bmin;
+		red[1][wv] = bmax;
+		red[2][wv] = bdmin;
+		red[3][wv] = bdmax;
+		red[4][wv] = ovf;
+		red[5][wv] = nvalid;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		for (int i = 1; i < kWorkgroup / 64; i++) {
+			bmin = red[0][i] < bmin ? red[0][i] : bmin;
+			bmax = red[1][i] > bmax ? red[1][i] : bmax;
+			bdmin = red[2][i] < bdmin ? red[2][i] : bdmin;
+			bdmax = red[3][i] > bdmax ? red[3][i] : bdmax;
+			ovf |= red[4][i];
+			nvalid += red[5][i];
+		}
+		BpStats s;
+		s.bmin = bmin;
+		s.bmax = bmax;
+		s.bdmin = bdmin;
+		s.bdmax = bdmax;
+		s.v0 = (uint64_t)vals[g0];
+		s.rows = rows;
+		s.nvalid = (uint32_t)nvalid;
+		s.delta_overflow = (uint32_t)ovf;
+		s.pad = 0;
+		stats[blockIdx.x] = s;
+	}
+}
+
+// What the host decided for one group (uploaded), consumed by k_bp_write.
+struct BpWrite {
+	uint64_t frame, extra; // FOR / DELTA_FOR frame of reference, CONSTANT's constant; delta / delta_offset
+	uint64_t first;        // value of the block's first 8 bytes (offset past the first group's metadata entry)
+	uint32_t seg;          // block index
+	uint32_t data_off;     // byte offset of the group's data in its block
+	uint32_t meta_off;     // byte offset of the group's metadata entry in its block
+	uint32_t mode, width, rows;
+	uint32_t first_of_segment;
+	uint32_t pad;
+};
+
+template <typename U>
+__device__ __forceinline__ void store_unaligned(uint8_t *p, U v) {
+#pragma unroll
+	for (int i = 0; i < (int)sizeof(U); i++) p[i] = (uint8_t)((uint64_t)v >> (8 * i));
+}
+
+template <typename U>
+__global__ __launch_bounds__(kWorkgroup) void k_bp_write(const BpWrite *__restrict__ recs, const U *__restrict__ vals,
+                                                         const uint64_t *__restrict__ validity, uint64_t block_stride,
+                                                         uint8_t *__restrict__ blocks) {
+	__shared__ __attribute__((aligned(16))) U fld[kBpGroupRows];
+	__shared__ uint32_t packed[kTileBytes / 4];
+	const BpWrite r = recs[blockIdx.x];
+	uint8_t *blk = blocks + (uint64_t)r.seg * block_stride;
+	uint8_t *p = blk + r.data_off;
+	const uint64_t g0 = (uint64_t)blockIdx.x * kBpGroupRows;
+	if (threadIdx.x == 0) {
+		// header (WriteData calls of the BitpackingWriter, bitpacking.cpp:374-437) + metadata entry (:447-451)
+		store_unaligned<U>(p, (U)r.frame);
+		if (r.mode == kBpConstantDelta) {
+			store_unaligned<U>(p + sizeof(U), (U)r.extra);
+		} else if (r.mode == kBpFor || r.mode == kBpDeltaFor) {
+			store_unaligned<U>(p + sizeof(U), (U)r.width);
+			if (r.mode == kBpDeltaFor) store_unaligned<U>(p + 2 * sizeof(U), (U)r.extra);
+		}
+		*reinterpret_cast<uint32_t *>(blk + r.meta_off) = r.data_off | (r.mode << 24);
+		if (r.first_of_segment) *reinterpret_cast<uint64_t *>(blk) = r.first;
+	}
+	if ((r.mode != kBpFor && r.mode != kBpDeltaFor) || r.width == 0) return;
+	uint8_t *payload = p + (r.mode == kBpDeltaFor ? 3 : 2) * sizeof(U);
+	const uint32_t w = r.width;
+	const uint32_t rows32 = (r.rows + 31u) & ~31u; // RoundUpToAlgorithmGroupSize: the tail group is zero-padded
+	const U frame = (U)r.frame;
+	for (uint32_t i = threadIdx.x; i < rows32; i += kWorkgroup) {
+		U f = 0;
+		if (i < r.rows) {
+			const uint64_t e = g0 + i;
+			if (r.mode == kBpFor) {
+				const bool valid = validity == nullptr || ((validity[e >> 6] >> (e & 63)) & 1ull);
+				const U x = valid ? vals[e] : (U)0;
+				f = (U)(x - frame); // SubtractFrameOfReference
+			} else {
+				f = i == 0 ? (U)0 : (U)((U)(vals[e] - vals[e - 1]) - frame); // delta_buffer[0] = minimum_delta
+			}
+		}
+		fld[i] = f;
+	}
+	__syncthreads();
+	// every lane owns whole 32-bit words of the group's bit stream and gathers the fields overlapping them
+	const uint32_t ndw = rows32 * w / 32;
+	const uint64_t fmask = w >= 64 ? ~0ull : ((1ull << w) - 1ull);
+	for (uint32_t q = threadIdx.x; q < ndw; q += kWorkgroup) {
+		const uint32_t bitlo = q * 32u;
+		uint32_t i = bitlo / w;
+		uint32_t last = (bitlo + 31u) / w;
+		last = last < rows32 ? last : rows32 - 1;
+		uint32_t acc = 0;
+		for (; i <= last; i++) {
+			const uint64_t v = (uint64_t)fld[i] & fmask; // fastpack masks every value to `width` bits
+			const int32_t pos = (int32_t)(i * w) - (int32_t)bitlo;
+			acc |= pos >= 0 ? (uint32_t)(v << pos) : (uint32_t)(v >> (-pos));
+		}
+		packed[q] = acc;
+	}
+	__syncthreads();
+	// the payload starts wherever the previous group ended: sizeof(T)-aligned only
+	const uintptr_t a = reinterpret_cast<uintptr_t>(payload);
+	if ((a & 3) == 0) {
+		uint32_t *dst = reinterpret_cast<uint32_t *>(payload);
+		for (uint32_t q = threadIdx.x; q < ndw; q += kWorkgroup) dst[q] = packed[q];
+	} else {
+		const uint8_t *src = reinterpret_cast<const uint8_t *>(packed);
+		for (uint32_t b = threadIdx.x; b < ndw * 4; b += kWorkgroup) payload[b] = src[b];
+	}
+}

@@ -652,3 +652,277 @@ extern "C" adac_status adac_bp_fetch_rows(adac_bp_layout *l, const void *d_block
 	ADAC_HIP(adac::launch_bp_fetch(l->ctx->stream, l->type_size, l->d_block_offs, d_blocks, d_segs, d_rows, n, d_out));
 	return ADAC_OK;
 }
+
+// ---- BITPACKING compress: device statistics + host decisions (BitpackingState::Flush) + device group writes ----
+
+namespace {
+
+struct BpType {
+	uint32_t ts, bits;
+	bool sg;
+	uint64_t mask, sbit;
+};
+
+inline int64_t bp_s64(const BpType &t, uint64_t x) {
+	x &= t.mask;
+	if (t.ts == 8) return (int64_t)x;
+	const uint64_t sb = 1ull << (t.bits - 1);
+	return (int64_t)((x ^ sb) - sb);
+}
+
+// TrySubtractOperator::Operation (src/function/scalar/operators/subtract.cpp:82-160) in T (as_signed = T's
+// signedness) or in T_S (as_signed = true)
+inline bool bp_try_sub(const BpType &t, bool as_signed, uint64_t l, uint64_t r, uint64_t *res) {
+	if (!as_signed) {
+		if ((r & t.mask) > (l & t.mask)) return false;
+		*res = (l - r) & t.mask;
+		return true;
+	}
+	if (t.ts == 8) {
+		int64_t o;
+		if (__builtin_sub_overflow((int64_t)l, (int64_t)r, &o)) return false;
+		*res = (uint64_t)o;
+		return true;
+	}
+	const int64_t d = bp_s64(t, l) - bp_s64(t, r);
+	const int64_t lim = (int64_t)(t.mask >> 1);
+	if (d < -lim - 1 || d > lim) return false;
+	*res = (uint64_t)d & t.mask;
+	return true;
+}
+
+inline uint32_t bp_eff_width(const BpType &t, uint32_t w) { // GetEffectiveWidth, bitpacking.hpp:208-216
+	return (w + t.ts > t.bits) ? t.bits : w;
+}
+inline uint32_t bp_width_unsigned(const BpType &t, uint64_t v) { // FindMinimumBitWidth<T_U>
+	v &= t.mask;
+	if (v == 0) return 0;
+	uint32_t w = 0;
+	while (v) {
+		w++;
+		v >>= 1;
+	}
+	return bp_eff_width(t, w);
+}
+inline uint32_t bp_width_signed(const BpType &t, uint64_t v) { // FindMinimumBitWidth<T> for a signed T
+	const uint64_t tmin = (~(t.mask >> 1)) & t.mask;
+	if ((v & t.mask) == tmin) return t.bits;
+	const int64_t s = bp_s64(t, v);
+	uint64_t mag = (uint64_t)(s < 0 ? -s : s);
+	if (mag == 0) return 0;
+	uint32_t w = 1;
+	while (mag) {
+		w++;
+		mag >>= 1;
+	}
+	return bp_eff_width(t, w);
+}
+inline uint64_t bp_required_size(uint64_t count, uint32_t w) { // GetRequiredSize, bitpacking.hpp:99-102
+	return ((count + 31) / 32 * 32) * w / 8;
+}
+
+constexpr uint64_t kBpBlock = 262144 - 8; // Storage::BLOCK_SIZE
+
+} // namespace
+
+struct adac_bp_plan {
+	adac_ctx *ctx = nullptr;
+	uint32_t type_size = 0;
+	bool is_signed = false;
+	uint64_t n = 0, ngroups = 0;
+	bool encodable = true;
+	struct Seg {
+		uint64_t start, count, total_size;
+	};
+	std::vector<Seg> segs;
+	uint64_t by_mode[5] = {0, 0, 0, 0, 0};
+	void *d_recs = nullptr;
+};
+
+extern "C" void adac_bp_plan_destroy(adac_bp_plan *p) {
+	if (!p) return;
+	(void)hipSetDevice(p->ctx->device);
+	if (p->d_recs) (void)hipFree(p->d_recs);
+	delete p;
+}
+
+extern "C" adac_status adac_bp_plan_create(adac_ctx *c, int physical_type, const void *d_vals, const uint64_t *d_validity,
+                                           uint64_t n, int force_mode, adac_bp_plan **out) {
+	if (!c || !out || (n && !d_vals) || force_mode < 0 || force_mode > 4) return ADAC_ERR_INVALID_ARGUMENT;
+	*out = nullptr;
+	if (!adac_type_is_supported(physical_type)) return ADAC_ERR_UNSUPPORTED_TYPE;
+	adac_bp_plan *p = new (std::nothrow) adac_bp_plan();
+	if (!p) return ADAC_ERR_OUT_OF_MEMORY;
+	p->ctx = c;
+	p->type_size = adac_type_size(physical_type);
+	p->is_signed = type_is_signed(physical_type);
+	p->n = n;
+	p->ngroups = (n + 2047) / 2048;
+	BpType t;
+	t.ts = p->type_size;
+	t.bits = 8 * t.ts;
+	t.sg = p->is_signed;
+	t.mask = t.ts == 8 ? ~0ull : ((1ull << t.bits) - 1ull);
+	t.sbit = t.sg ? (1ull << (t.bits - 1)) : 0ull;
+	const uint64_t sbit_s = 1ull << (t.bits - 1);
+	const uint64_t ts_max = t.mask >> 1;                  // NumericLimits<T_S>::Maximum()
+	const uint64_t t_max = t.sg ? ts_max : t.mask;
+	const uint64_t t_min = t.sg ? ((~ts_max) & t.mask) : 0ull;
+
+	std::vector<adac::BpStatsHost> stats(p->ngroups);
+	void *d_stats = nullptr;
+	hipError_t e = hipSetDevice(c->device);
+	if (e == hipSuccess && p->ngroups) e = hipMalloc(&d_stats, p->ngroups * sizeof(adac::BpStatsHost));
+	if (e == hipSuccess) e = adac::launch_bp_stats(c->stream, p->type_size, p->is_signed, d_vals, d_validity, n, d_stats);
+	if (e == hipSuccess && p->ngroups)
+		e = hipMemcpyAsync(stats.data(), d_stats, p->ngroups * sizeof(adac::BpStatsHost), hipMemcpyDeviceToHost, c->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	if (d_stats) (void)hipFree(d_stats);
+	if (e != hipSuccess) {
+		adac_status st = fail_hip(e, "adac_bp_plan_create");
+		adac_bp_plan_destroy(p);
+		return st;
+	}
+
+	// BitpackingState::Flush per group (bitpacking.cpp:229-294) + ReserveSpace / FlushSegment placement (:453-512)
+	std::vector<adac::BpWriteHost> recs(p->ngroups);
+	uint64_t data_ptr = 8, meta_ptr = kBpBlock, seg_first_group = 0, seg_start = 0, seg_count = 0;
+	auto finish_segment = [&](uint64_t end_group) {
+		const uint64_t metadata_offset = (data_ptr + 7) & ~7ull;
+		const uint64_t k = end_group - seg_first_group;
+		const uint64_t total = metadata_offset + 4 * k;
+		for (uint64_t g = seg_first_group; g < end_group; g++) {
+			recs[g].meta_off = (uint32_t)(total - 4 * (g - seg_first_group + 1));
+			recs[g].first = total;
+			recs[g].first_of_segment = g == seg_first_group;
+		}
+		p->segs.push_back(adac_bp_plan::Seg {seg_start, seg_count, total});
+	};
+	for (uint64_t g = 0; g < p->ngroups; g++) {
+		const adac::BpStatsHost &st = stats[g];
+		adac::BpWriteHost &r = recs[g];
+		std::memset(&r, 0, sizeof(r));
+		const uint64_t rows = st.rows;
+		const bool all_invalid = st.nvalid == 0, all_valid = st.nvalid == rows;
+		const uint64_t minimum = all_invalid ? t_max : ((st.bmin ^ t.sbit) & t.mask);
+		const uint64_t maximum = all_invalid ? t_min : ((st.bmax ^ t.sbit) & t.mask);
+		uint64_t bytes = 0;
+		bool done = false;
+		if ((all_invalid || maximum == minimum) && (force_mode == 0 || force_mode == 1)) {
+			r.mode = 1;
+			r.frame = maximum;
+			bytes = t.ts;
+			done = true;
+		}
+		uint64_t mmd = 0, mmdd = 0, delta_offset = 0, min_delta = 0, max_delta = 0;
+		bool can_do_for = false, can_do_delta = false;
+		if (!done) {
+			can_do_for = bp_try_sub(t, t.sg, maximum, minimum, &mmd);
+			const bool above = !t.sg && maximum > ts_max; // maximum > (T)NumericLimits<T_S>::Maximum()
+			if (!above && rows >= 2 && all_valid) {
+				bool can_do_all = true;
+				if (t.sg) {
+					uint64_t bogus;
+					can_do_all = bp_try_sub(t, true, minimum, maximum, &bogus) && bp_try_sub(t, true, maximum, minimum, &bogus);
+				}
+				if (can_do_all || !st.delta_overflow) {
+					min_delta = (st.bdmin ^ sbit_s) & t.mask;
+					max_delta = (st.bdmax ^ sbit_s) & t.mask;
+					can_do_delta = bp_try_sub(t, true, max_delta, min_delta, &mmdd);
+					can_do_delta = can_do_delta && bp_try_sub(t, true, st.v0, min_delta, &delta_offset);
+				}
+			}
+			if (can_do_delta) {
+				if (max_delta == min_delta && force_mode != 4 && force_mode != 3) {
+					r.mode = 2;
+					r.frame = st.v0;
+					r.extra = max_delta;
+					bytes = 2 * t.ts;
+					done = true;
+				} else {
+					const uint32_t dw = bp_width_unsigned(t, mmdd);
+					const uint32_t rw = t.sg ? bp_width_signed(t, mmd) : bp_width_unsigned(t, mmd);
+					if (dw < rw && force_mode != 4) {
+						r.mode = 3;
+						r.frame = min_delta;
+						r.width = dw;
+						r.extra = delta_offset;
+						bytes = bp_required_size(rows, dw) + 3 * t.ts;
+						done = true;
+					}
+				}
+			}
+			if (!done && can_do_for) {
+				r.mode = 4;
+				r.frame = minimum;
+				r.width = bp_width_unsigned(t, mmd);
+				bytes = bp_required_size(rows, r.width) + 2 * t.ts;
+				done = true;
+			}
+		}
+		if (!done) {
+			p->encodable = false; // Flush() returned false: BitpackingFinalAnalyze reports INVALID_INDEX
+			break;
+		}
+		if (meta_ptr - data_ptr < bytes + 4) { // FlushAndCreateSegmentIfFull
+			finish_segment(g);
+			seg_first_group = g;
+			seg_start += seg_count;
+			seg_count = 0;
+			data_ptr = 8;
+			meta_ptr = kBpBlock;
+		}
+		r.seg = (uint32_t)p->segs.size();
+		r.data_off = (uint32_t)data_ptr;
+		r.rows = (uint32_t)rows;
+		data_ptr += bytes;
+		meta_ptr -= 4;
+		seg_count += rows;
+		p->by_mode[r.mode]++;
+	}
+	if (p->encodable) {
+		finish_segment(p->ngroups);
+		if (p->ngroups) {
+			e = hipMalloc(&p->d_recs, p->ngroups * sizeof(adac::BpWriteHost));
+			if (e == hipSuccess)
+				e = hipMemcpyAsync(p->d_recs, recs.data(), p->ngroups * sizeof(adac::BpWriteHost), hipMemcpyHostToDevice,
+				                   c->stream);
+			if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+			if (e != hipSuccess) {
+				adac_status st2 = fail_hip(e, "adac_bp_plan_create(upload)");
+				adac_bp_plan_destroy(p);
+				return st2;
+			}
+		}
+	} else {
+		p->segs.clear();
+	}
+	*out = p;
+	return ADAC_OK;
+}
+
+extern "C" int adac_bp_plan_encodable(const adac_bp_plan *p) { return p && p->encodable ? 1 : 0; }
+extern "C" uint64_t adac_bp_plan_nseg(const adac_bp_plan *p) { return p ? p->segs.size() : 0; }
+extern "C" uint64_t adac_bp_plan_groups_by_mode(const adac_bp_plan *p, int mode) {
+	return (p && mode >= 1 && mode <= 4) ? p->by_mode[mode] : 0;
+}
+extern "C" adac_status adac_bp_plan_segment(const adac_bp_plan *p, uint64_t i, uint64_t *start, uint64_t *count,
+                                            uint64_t *total_size) {
+	if (!p || i >= p->segs.size()) return ADAC_ERR_INVALID_ARGUMENT;
+	if (start) *start = p->segs[i].start;
+	if (count) *count = p->segs[i].count;
+	if (total_size) *total_size = p->segs[i].total_size;
+	return ADAC_OK;
+}
+
+extern "C" adac_status adac_bp_write(adac_bp_plan *p, const void *d_vals, const uint64_t *d_validity, void *d_blocks,
+                                     uint64_t block_stride) {
+	if (!p || !p->encodable || (p->n && (!d_vals || !d_blocks))) return ADAC_ERR_INVALID_ARGUMENT;
+	if (block_stride < kBpBlock || (block_stride & 15) || !aligned16(d_blocks)) return ADAC_ERR_INVALID_ARGUMENT;
+	ADAC_HIP(hipSetDevice(p->ctx->device));
+	// alignment gaps and unused tails are zero (the reference leaves them as the buffer manager handed them out)
+	if (!p->segs.empty()) ADAC_HIP(hipMemsetAsync(d_blocks, 0, p->segs.size() * block_stride, p->ctx->stream));
+	ADAC_HIP(adac::launch_bp_write(p->ctx->stream, p->type_size, p->d_recs, p->ngroups, d_vals, d_validity, block_stride,
+	                               d_blocks));
+	return ADAC_OK;
+}

@@ -74,6 +74,20 @@ struct BpGroupHost {
 	uint64_t payload_off, frame, extra; // parsed header, filled on the device by launch_bp_prepare
 	uint32_t mode, width;
 };
+// compress side: per-group statistics (device -> host) and write records (host -> device); must match
+// BpStats / BpWrite in adac_bitpacking.inl
+struct BpStatsHost {
+	uint64_t bmin, bmax, bdmin, bdmax, v0;
+	uint32_t rows, nvalid, delta_overflow, pad;
+};
+struct BpWriteHost {
+	uint64_t frame, extra, first;
+	uint32_t seg, data_off, meta_off, mode, width, rows, first_of_segment, pad;
+};
+hipError_t launch_bp_stats(hipStream_t s, uint32_t type_size, bool is_signed, const void *d_vals,
+                           const uint64_t *d_validity, uint64_t n, void *d_stats);
+hipError_t launch_bp_write(hipStream_t s, uint32_t type_size, const void *d_recs, uint64_t ngroups, const void *d_vals,
+                           const uint64_t *d_validity, uint64_t block_stride, void *d_blocks);
 hipError_t launch_bp_prepare(hipStream_t s, uint32_t type_size, void *d_groups, uint64_t ngroups, const void *d_blocks);
 hipError_t launch_bp_unpack(hipStream_t s, uint32_t type_size, const void *d_groups, uint64_t ngroups,
                             const void *d_blocks, void *d_out);

@@ -1053,6 +1053,31 @@ hipError_t launch_bp_prepare(hipStream_t s, uint32_t type_size, void *d_groups, 
 	});
 }
 
+hipError_t launch_bp_stats(hipStream_t s, uint32_t type_size, bool is_signed, const void *d_vals,
+                           const uint64_t *d_validity, uint64_t n, void *d_stats) {
+	if (n == 0) return hipSuccess;
+	const uint64_t ngroups = (n + kBpGroupRows - 1) / kBpGroupRows;
+	return dispatch_size(type_size, [&](auto tag) {
+		using U = decltype(tag);
+		const uint64_t sbit = is_signed ? (1ull << (8 * sizeof(U) - 1)) : 0ull;
+		hipLaunchKernelGGL(k_bp_stats<U>, dim3((unsigned)ngroups), dim3(kWorkgroup), 0, s, static_cast<const U *>(d_vals),
+		                   d_validity, n, sbit, static_cast<BpStats *>(d_stats));
+		return hipGetLastError();
+	});
+}
+
+hipError_t launch_bp_write(hipStream_t s, uint32_t type_size, const void *d_recs, uint64_t ngroups, const void *d_vals,
+                           const uint64_t *d_validity, uint64_t block_stride, void *d_blocks) {
+	if (ngroups == 0) return hipSuccess;
+	return dispatch_size(type_size, [&](auto tag) {
+		using U = decltype(tag);
+		hipLaunchKernelGGL(k_bp_write<U>, dim3((unsigned)ngroups), dim3(kWorkgroup), 0, s,
+		                   static_cast<const BpWrite *>(d_recs), static_cast<const U *>(d_vals), d_validity, block_stride,
+		                   static_cast<uint8_t *>(d_blocks));
+		return hipGetLastError();
+	});
+}
+
 hipError_t launch_bp_unpack(hipStream_t s, uint32_t type_size, const void *d_groups, uint64_t ngroups,
                             const void *d_blocks, void *d_out) {
 	if (ngroups == 0) return hipSuccess;

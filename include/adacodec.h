@@ -270,6 +270,27 @@ adac_status adac_bp_unpack(adac_bp_layout *l, const void *d_blocks, void *d_out)
 adac_status adac_bp_fetch_rows(adac_bp_layout *l, const void *d_blocks, const uint32_t *d_segs, const uint32_t *d_rows,
                                uint64_t n, void *d_out);
 
+/* Compress side (BitpackingCompress / BitpackingFinalizeCompress, bitpacking.cpp:514-538): per-group statistics
+ * on the device, the mode decision of BitpackingState::Flush (:229-294) and the sequential placement of groups
+ * into Storage::BLOCK_SIZE blocks (:453-512) on the host, then one device pass writing every group image.
+ * force_mode: BitpackingMode (0 AUTO, 1 CONSTANT, 2 CONSTANT_DELTA, 3 DELTA_FOR, 4 FOR — the reference's
+ * force_bitpacking_mode).  NULL rows are encoded as the value 0 (the reference leaves them indeterminate). */
+typedef struct adac_bp_plan adac_bp_plan;
+adac_status adac_bp_plan_create(adac_ctx *ctx, int physical_type, const void *d_vals, const uint64_t *d_validity,
+                                uint64_t n, int force_mode, adac_bp_plan **out);
+void adac_bp_plan_destroy(adac_bp_plan *p);
+/* 0 when some group can be stored in no mode (Flush() == false: BitpackingFinalAnalyze returns INVALID_INDEX) */
+int adac_bp_plan_encodable(const adac_bp_plan *p);
+uint64_t adac_bp_plan_nseg(const adac_bp_plan *p);
+uint64_t adac_bp_plan_groups_by_mode(const adac_bp_plan *p, int mode);
+/* first row, row count and used bytes (FlushSegment's total_segment_size) of segment i */
+adac_status adac_bp_plan_segment(const adac_bp_plan *p, uint64_t i, uint64_t *start, uint64_t *count,
+                                 uint64_t *total_size);
+/* Write every segment's block image: segment i at d_blocks + i*block_stride (block_stride >= 262136, multiple of 16).
+ * The whole nseg*block_stride range is rewritten (unused bytes zero). */
+adac_status adac_bp_write(adac_bp_plan *p, const void *d_vals, const uint64_t *d_validity, void *d_blocks,
+                          uint64_t block_stride);
+
 #ifdef __cplusplus
 }
 #endif

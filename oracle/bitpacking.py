@@ -30,7 +30,7 @@ def lib():
         u64, vp, i32, u32 = C.c_uint64, C.c_void_p, C.c_int, C.c_uint
         for name, res, args in (
             ("bp_pack_group", None, [vp, u32, vp]), ("bp_unpack_group", None, [vp, u32, vp]),
-            ("bp_compress", vp, [vp, vp, u64, u32, i32, i32]), ("bp_free", None, [vp]),
+            ("bp_compress", vp, [vp, vp, u64, u32, i32, i32, i32]), ("bp_free", None, [vp]),
             ("bp_num_segments", u64, [vp]), ("bp_segment_block", vp, [vp, u64]), ("bp_segment_count", u64, [vp, u64]),
             ("bp_segment_start", u64, [vp, u64]), ("bp_segment_size", u64, [vp, u64]),
             ("bp_groups_by_mode", u64, [vp, i32]), ("bp_scan", None, [vp, u32, i32, u64, u64, u64, vp]),
@@ -68,13 +68,13 @@ def unpack_group(buf, w):
 class Compressed:
     """A column compressed into BITPACKING segments (256 KiB block images)."""
 
-    def __init__(self, vals, validity=None, force_mode=MODE_AUTO):
+    def __init__(self, vals, validity=None, force_mode=MODE_AUTO, null_zero=False):
         vals = np.ascontiguousarray(vals)
         self.dtype = vals.dtype
         self.n = len(vals)
         v8 = None if validity is None else np.ascontiguousarray(validity, dtype=np.uint8)
         self._h = lib().bp_compress(vals.ctypes.data, None if v8 is None else v8.ctypes.data, self.n,
-                                    vals.dtype.itemsize, int(vals.dtype.kind == "i"), force_mode)
+                                    vals.dtype.itemsize, int(vals.dtype.kind == "i"), force_mode, int(null_zero))
         if not self._h:
             raise ValueError("the BITPACKING codec cannot encode this column (Flush returned false)")
 

@@ -161,6 +161,7 @@ typedef struct {
 typedef struct {
 	ty t;
 	int force_mode;
+	int null_zero; /* NULL rows take the value 0 instead of keeping the buffer's stale content */
 	/* BitpackingState */
 	uint64_t buf_internal[BP_GROUP + 1];
 	uint64_t *buf; /* = buf_internal + 1 */
@@ -348,6 +349,8 @@ static void st_update(bp_state *s, uint64_t value, int is_valid) { /* Update :29
 		s->buf[s->idx] = value;
 		if (lt_t(s->t, value, s->minimum)) s->minimum = value;
 		if (lt_t(s->t, s->maximum, value)) s->maximum = value;
+	} else if (s->null_zero) {
+		s->buf[s->idx] = 0;
 	}
 	s->idx++;
 	if (s->idx == BP_GROUP) {
@@ -360,10 +363,11 @@ static void st_update(bp_state *s, uint64_t value, int is_valid) { /* Update :29
  * BitpackingFinalizeCompress drive the state.  Returns an opaque handle, NULL if the codec cannot encode the
  * data (Flush returned false: BitpackingFinalAnalyze would have reported INVALID_INDEX). */
 ORC_API bp_state *bp_compress(const void *vals, const uint8_t *validity, uint64_t n, unsigned type_size, int is_signed,
-                              int force_mode) {
+                              int force_mode, int null_zero) {
 	bp_state *s = (bp_state *)calloc(1, sizeof(bp_state));
 	s->t = mk_ty(type_size, is_signed);
 	s->force_mode = force_mode;
+	s->null_zero = null_zero;
 	s->buf = s->buf_internal + 1;
 	st_reset(s);
 	create_segment(s, 0);

@@ -144,3 +144,85 @@ def test_nulls_multi_segment_and_output_placement(adac, gpu_ctx):
         adac.BitpackingLayout(gpu_ctx, np.int32, np.array([8], dtype=np.uint64), np.array([10], dtype=np.uint32))
     with pytest.raises(adac.AdacError):
         adac.BitpackingLayout(gpu_ctx, np.float32, offs, counts)
+
+
+def gpu_compress(adac, ctx, v, valid=None, force_mode=0):
+    d_vals = ctx.upload(v)
+    d_valid = None
+    if valid is not None:
+        bits = np.packbits(valid, bitorder="little")
+        bits = np.concatenate([bits, np.zeros((-len(bits)) % 8 + 8, np.uint8)]).view(np.uint64)
+        d_valid = ctx.upload(bits)
+    plan = adac.BitpackingPlan(ctx, v.dtype, d_vals, len(v), d_valid, force_mode)
+    if not plan.encodable:
+        return plan, None, d_vals
+    d_blocks = ctx.alloc(max(plan.nseg, 1) * plan.BLOCK_STRIDE + 64)
+    plan.write(d_vals, d_blocks, d_valid)
+    ctx.sync()
+    return plan, d_blocks, d_vals
+
+
+def assert_blocks_equal_oracle(plan, d_blocks, comp):
+    assert plan.nseg == comp.nseg
+    assert plan.groups_by_mode() == comp.groups_by_mode()
+    img = d_blocks.download(np.uint8, plan.nseg * plan.BLOCK_STRIDE)
+    for i in range(comp.nseg):
+        start, count, size = plan.segment(i)
+        assert (start, count, size) == (comp.start(i), comp.count(i), comp.size(i)), i
+        got = img[i * plan.BLOCK_STRIDE:i * plan.BLOCK_STRIDE + size]
+        exp = comp.block(i)[:size]
+        if not np.array_equal(got, exp):
+            bad = np.nonzero(got != exp)[0]
+            raise AssertionError("segment %d differs at bytes %s" % (i, bad[:10]))
+
+
+@pytest.mark.parametrize("dtype", ALL)
+def test_gpu_compress_writes_the_reference_block_image(adac, gpu_ctx, dtype):
+    """adac_bp_plan_create + adac_bp_write against the oracle's restatement of BitpackingCompress: identical
+    segment boundaries, mode per group and block bytes; then the device decodes its own blocks."""
+    rng = np.random.default_rng(200 + np.dtype(dtype).itemsize)
+    v = mixed_column(dtype, rng, groups=14)
+    plan, d_blocks, _ = gpu_compress(adac, gpu_ctx, v)
+    comp = bp.Compressed(v)
+    assert_blocks_equal_oracle(plan, d_blocks, comp)
+    counts = np.array([plan.segment(i)[1] for i in range(plan.nseg)], dtype=np.uint32)
+    lay = adac.BitpackingLayout(gpu_ctx, dtype, np.arange(plan.nseg, dtype=np.uint64) * plan.BLOCK_STRIDE, counts)
+    d_out = gpu_ctx.alloc(len(v) * v.dtype.itemsize + 64)
+    lay.unpack(d_blocks, d_out)
+    assert np.array_equal(d_out.download(v.dtype, len(v)), v)
+
+
+def test_gpu_compress_forced_modes_nulls_and_many_segments(adac, gpu_ctx):
+    rng = np.random.default_rng(77)
+    # forced modes (the reference's force_bitpacking_mode test knob)
+    v = (10_000 + np.cumsum(rng.integers(0, 900, size=40_000))).astype(np.int64)
+    for mode in (bp.MODE_FOR, bp.MODE_DELTA_FOR, bp.MODE_CONSTANT_DELTA, bp.MODE_CONSTANT):
+        plan, d_blocks, _ = gpu_compress(adac, gpu_ctx, v, force_mode=mode)
+        assert_blocks_equal_oracle(plan, d_blocks, bp.Compressed(v, force_mode=mode))
+    # NULL rows (stored as the value 0; oracle in the same convention) over several 256 KiB blocks
+    n = 900_000
+    v = (3_000_000 + rng.integers(0, 1 << 25, size=n)).astype(np.uint32)
+    valid = rng.random(n) > 0.2
+    valid[4096:8192] = False
+    plan, d_blocks, _ = gpu_compress(adac, gpu_ctx, v, valid)
+    comp = bp.Compressed(v, valid, null_zero=True)
+    assert comp.nseg >= 4
+    assert_blocks_equal_oracle(plan, d_blocks, comp)
+    # 8- and 16-bit columns: group payloads start at odd byte offsets
+    for dtype in (np.uint8, np.int16):
+        info = np.iinfo(dtype)
+        parts = []
+        for g in range(40):
+            if g % 3 == 0:
+                parts.append(np.full(2048, g % 50, dtype=np.int64))
+            else:
+                parts.append(rng.integers(0, max(2, int(info.max) >> (g % 5 + 1)), size=2048))
+        v = np.concatenate(parts).astype(dtype)
+        plan, d_blocks, _ = gpu_compress(adac, gpu_ctx, v)
+        assert_blocks_equal_oracle(plan, d_blocks, bp.Compressed(v))
+    # a column no mode can hold: Flush() == false
+    bad = np.array([np.iinfo(np.int64).min, np.iinfo(np.int64).max] * 2048, dtype=np.int64)
+    plan, d_blocks, _ = gpu_compress(adac, gpu_ctx, bad)
+    assert not plan.encodable and d_blocks is None and plan.nseg == 0
+    with pytest.raises(ValueError):
+        bp.Compressed(bad)
