@@ -126,7 +126,21 @@ def bitpacking_scan(adac, n=50_000_000):
         for _ in range(reps):
             lay.unpack(d_blocks, d_out)
         ms = ctx.timer_stop() / reps
+        # GPU compress of the same column: statistics + host decisions + group writes (wall time, host included)
+        d_vals = ctx.upload(v)
+        t0 = time.perf_counter()
+        plan = adac.BitpackingPlan(ctx, v.dtype, d_vals, n)
+        d_new = ctx.alloc(plan.nseg * plan.BLOCK_STRIDE + 64)
+        plan.write(d_vals, d_new)
+        ctx.sync()
+        t_gpu_compress = time.perf_counter() - t0
+        assert plan.nseg == nseg and plan.groups_by_mode() == comp.groups_by_mode()
+        img = d_new.download(np.uint8, nseg * plan.BLOCK_STRIDE)
+        assert all(np.array_equal(img[i * stride:i * stride + comp.size(i)], comp.block(i)[:comp.size(i)])
+                   for i in range(0, nseg, max(1, nseg // 16)))
+        del d_new, d_vals, plan
         out["cases"].append({
+            "gpu_compress_values_per_s": n / t_gpu_compress, "gpu_compress_s": t_gpu_compress,
             "name": name, "dtype": str(v.dtype), "segments": nseg, "compressed_bytes": used,
             "modes": comp.groups_by_mode(), "cpu_compress_values_per_s": n / t_cpu, "decode_ms": ms,
             "decode_values_per_s": n / (ms * 1e-3),
