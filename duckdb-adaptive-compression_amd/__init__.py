@@ -126,6 +126,8 @@ SIGNATURES = {
     "adac_scan_sum": (_int, [_vp, _vp, _vp]),
     "adac_scan_count_eq": (_int, [_vp, _vp, _u64, _vp]),
     "adac_scan_count_between": (_int, [_vp, _vp, _u64, _u64, _vp]),
+    "adac_scan_sum_valid": (_int, [_vp, _vp, _vp, _vp]),
+    "adac_scan_count_between_valid": (_int, [_vp, _vp, _vp, _u64, _u64, _vp]),
     "adac_bp_layout_create": (_int, [_vp, _int, _vp, _vp, _vp, _u64, _P(_vp)]),
     "adac_bp_layout_destroy": (None, [_vp]),
     "adac_bp_layout_ngroups": (_u64, [_vp]),
@@ -385,13 +387,13 @@ class Layout:
         _check(lib().adac_fetch_rows(self._h, _dptr(d_words), _dptr(d_segs), _dptr(d_rows), n, _dptr(d_out)),
                "adac_fetch_rows")
 
-    def scan_sum(self, d_words, d_sums):
-        _check(lib().adac_scan_sum(self._h, _dptr(d_words), _dptr(d_sums)), "adac_scan_sum")
+    def scan_sum(self, d_words, d_sums, d_validity=None):
+        _check(lib().adac_scan_sum_valid(self._h, _dptr(d_words), _dptr(d_validity), _dptr(d_sums)), "adac_scan_sum")
 
-    def scan_count_between(self, d_words, lo, hi, d_counts):
+    def scan_count_between(self, d_words, lo, hi, d_counts, d_validity=None):
         """lo / hi: bit patterns of the column type (use int(np.array([v], dtype).view(unsigned)[0]) for signed)."""
-        _check(lib().adac_scan_count_between(self._h, _dptr(d_words), lo & NO_MIN, hi & NO_MIN, _dptr(d_counts)),
-               "adac_scan_count_between")
+        _check(lib().adac_scan_count_between_valid(self._h, _dptr(d_words), _dptr(d_validity), lo & NO_MIN, hi & NO_MIN,
+                                                   _dptr(d_counts)), "adac_scan_count_between")
 
     def scan_count_eq(self, d_words, key, d_counts):
         _check(lib().adac_scan_count_eq(self._h, _dptr(d_words), key & NO_MIN, _dptr(d_counts)), "adac_scan_count_eq")

@@ -518,17 +518,34 @@ extern "C" adac_status adac_fetch_rows(adac_layout *l, const uint64_t *d_words, 
 	return ADAC_OK;
 }
 
+extern "C" adac_status adac_scan_sum_valid(adac_layout *l, const uint64_t *d_words, const uint64_t *d_validity,
+                                           uint64_t *d_sums);
 extern "C" adac_status adac_scan_sum(adac_layout *l, const uint64_t *d_words, uint64_t *d_sums) {
+	return adac_scan_sum_valid(l, d_words, nullptr, d_sums);
+}
+
+extern "C" adac_status adac_scan_sum_valid(adac_layout *l, const uint64_t *d_words, const uint64_t *d_validity,
+                                           uint64_t *d_sums) {
 	if (!l || (l->nseg && !d_sums) || (l->total_values && !d_words)) return ADAC_ERR_INVALID_ARGUMENT;
 	if (!aligned16(d_words)) return ADAC_ERR_INVALID_ARGUMENT;
 	ADAC_HIP(hipSetDevice(l->ctx->device));
 	if (l->nseg) ADAC_HIP(hipMemsetAsync(d_sums, 0, l->nseg * sizeof(uint64_t), l->ctx->stream));
-	ADAC_HIP(adac::launch_scan_sum(l->ctx->stream, l->type_size, l->d_descs, l->d_tiles, l->ntiles, d_words, d_sums));
+	ADAC_HIP(adac::launch_scan_sum(l->ctx->stream, l->type_size, l->d_descs, l->d_tiles, l->ntiles, d_words, d_validity,
+	                               d_sums));
 	return ADAC_OK;
 }
 
+extern "C" adac_status adac_scan_count_between_valid(adac_layout *l, const uint64_t *d_words,
+                                                     const uint64_t *d_validity, uint64_t lo, uint64_t hi,
+                                                     uint64_t *d_counts);
 extern "C" adac_status adac_scan_count_between(adac_layout *l, const uint64_t *d_words, uint64_t lo, uint64_t hi,
                                                uint64_t *d_counts) {
+	return adac_scan_count_between_valid(l, d_words, nullptr, lo, hi, d_counts);
+}
+
+extern "C" adac_status adac_scan_count_between_valid(adac_layout *l, const uint64_t *d_words,
+                                                     const uint64_t *d_validity, uint64_t lo, uint64_t hi,
+                                                     uint64_t *d_counts) {
 	if (!l || (l->nseg && !d_counts) || (l->total_values && !d_words)) return ADAC_ERR_INVALID_ARGUMENT;
 	if (!aligned16(d_words)) return ADAC_ERR_INVALID_ARGUMENT;
 	ADAC_HIP(hipSetDevice(l->ctx->device));
@@ -539,8 +556,8 @@ extern "C" adac_status adac_scan_count_between(adac_layout *l, const uint64_t *d
 	const uint64_t sbit = l->is_signed ? (1ull << (bits - 1)) : 0ull;
 	const uint64_t blo = (lo & umask) ^ sbit, bhi = (hi & umask) ^ sbit;
 	if (bhi < blo) return ADAC_OK; // empty range: all counts stay zero
-	ADAC_HIP(adac::launch_scan_count_range(l->ctx->stream, l->type_size, l->d_descs, l->d_tiles, l->ntiles, d_words, blo,
-	                                       bhi - blo, sbit, d_counts));
+	ADAC_HIP(adac::launch_scan_count_range(l->ctx->stream, l->type_size, l->d_descs, l->d_tiles, l->ntiles, d_words,
+	                                       d_validity, blo, bhi - blo, sbit, d_counts));
 	return ADAC_OK;
 }
 

@@ -307,7 +307,7 @@ __device__ __forceinline__ void decode_run(const uint32_t *lds32, uint32_t bit0,
 				vals[j] = (U)(lo + add_lo);
 			}
 		}
-		sink(0, vals, true);
+		sink((int32_t)(r * PER_ROUND + threadIdx.x * K), vals, true);
 		bit += step;
 	}
 }
@@ -374,26 +374,38 @@ struct ChunkAgg {
 	static constexpr bool kFields32 = ((uint64_t)MAXV << W) <= 0xffffffffull; // MAXV fields fit a u32 sum
 	uint32_t p32 = 0;
 	uint64_t p64 = 0;
-	__device__ __forceinline__ void add(uint32_t f, uint32_t add_lo, const FieldRange &fr) {
+	uint32_t nvalid = 0; // rows aggregated (u64 SUM adds nvalid * min at the end)
+	__device__ __forceinline__ void add(uint32_t f, uint32_t add_lo, const FieldRange &fr, bool valid = true) {
+		const uint32_t m = valid ? 0xffffffffu : 0u;
+		nvalid += m & 1u;
 		if (OP == 1) {
-			p32 += (((f ^ fr.fxor) - fr.flo) <= fr.span) ? 1u : 0u; // the predicate, on the packed field
+			p32 += ((((f ^ fr.fxor) - fr.flo) <= fr.span) ? 1u : 0u) & m; // the predicate, on the packed field
 		} else if (sizeof(U) == 8) {
-			if (kFields32) p32 += f; else p64 += f;
+			if (kFields32) p32 += f & m; else p64 += f & m;
 		} else if (sizeof(U) == 4) {
-			p64 += (uint32_t)(f + add_lo);
+			p64 += (uint32_t)(f + add_lo) & m;
 		} else {
-			p32 += (uint32_t)(U)(f + add_lo); // <= 32 values of <= 16 bits
+			p32 += (uint32_t)(U)(f + add_lo) & m; // <= 32 values of <= 16 bits
 		}
 	}
-	__device__ __forceinline__ uint64_t total(uint32_t nv, uint64_t add) const {
-		if (OP == 0 && sizeof(U) == 8) return (uint64_t)p32 + p64 + (uint64_t)nv * add;
+	__device__ __forceinline__ uint64_t total(uint64_t add) const {
+		if (OP == 0 && sizeof(U) == 8) return (uint64_t)p32 + p64 + (uint64_t)nvalid * add;
 		return (uint64_t)p32 + p64;
 	}
 };
 
-template <int W, typename U, int OP>
+// `bits` validity bits starting at element index e (bit j of the result = element e + j), bits <= 32
+__device__ __forceinline__ uint32_t validity_window(const uint64_t *__restrict__ validity, uint64_t e) {
+	const uint32_t sh = (uint32_t)(e & 63);
+	uint64_t wnd = validity[e >> 6] >> sh;
+	if (sh > 32) wnd |= validity[(e >> 6) + 1] << (64 - sh);
+	return (uint32_t)wnd;
+}
+
+template <int W, typename U, int OP, bool V>
 __device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint32_t r0, uint32_t r1,
-                                           const adac_segment_desc &d, const RangePred &pred, uint64_t &acc) {
+                                           const adac_segment_desc &d, const RangePred &pred,
+                                           const uint64_t *__restrict__ validity, uint64_t &acc) {
 	constexpr int MAXV = (128 + W - 1) / W;
 	constexpr uint32_t mask = W >= 32 ? 0xffffffffu : ((1u << W) - 1u);
 	const uint32_t c0 = (uint32_t)(((uint64_t)r0 * W) >> 7);       // r0 is a multiple of 128 rows
@@ -433,29 +445,30 @@ __device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint
 		const uint32_t starting = (128u - o0 + (W - 1)) / W; // rows starting in the chunk: MAXV-1 or MAXV
 		const uint32_t lim = r1 > i0 ? r1 - i0 : 0u;
 		ChunkAgg<W, U, OP> agg;
-		uint32_t nv;
+		// NULL rows (DuckDB validity mask over the element index space) take no part in the aggregate
+		const uint32_t vbits = V ? validity_window(validity, d.val_off + i0) : 0xffffffffu;
 		if (starting <= lim) { // interior chunk: only the last slot may be absent
-			nv = starting;
 #pragma unroll
-			for (int j = 0; j < MAXV - 1; j++) agg.add(field_of<W>(nrm, j), add_lo, fr);
-			if (128 % W == 0 || starting == (uint32_t)MAXV) agg.add(field_of<W>(nrm, MAXV - 1), add_lo, fr);
+			for (int j = 0; j < MAXV - 1; j++) agg.add(field_of<W>(nrm, j), add_lo, fr, !V || ((vbits >> j) & 1u));
+			if (128 % W == 0 || starting == (uint32_t)MAXV) {
+				agg.add(field_of<W>(nrm, MAXV - 1), add_lo, fr, !V || ((vbits >> (MAXV - 1)) & 1u));
+			}
 		} else { // the run ends inside this chunk
-			nv = lim;
 #pragma unroll
 			for (int j = 0; j < MAXV; j++) {
-				if ((uint32_t)j < nv) agg.add(field_of<W>(nrm, j), add_lo, fr);
+				if ((uint32_t)j < lim) agg.add(field_of<W>(nrm, j), add_lo, fr, !V || ((vbits >> j) & 1u));
 			}
 		}
-		acc += agg.total(nv, add);
+		acc += agg.total(add);
 	}
 }
 
-template <typename U, int OP>
+template <typename U, int OP, bool V>
 __device__ __forceinline__ void scan_run_dispatch(uint32_t w, const uint4 *__restrict__ seg16, uint32_t r0,
                                                   uint32_t r1, const adac_segment_desc &d, const RangePred &pred,
-                                                  uint64_t &acc) {
+                                                  const uint64_t *__restrict__ validity, uint64_t &acc) {
 	switch (w) {
-#define ADAC_W(N) case N: scan_run_w<N, U, OP>(seg16, r0, r1, d, pred, acc); break;
+#define ADAC_W(N) case N: scan_run_w<N, U, OP, V>(seg16, r0, r1, d, pred, validity, acc); break;
 		ADAC_W(4) ADAC_W(5) ADAC_W(6) ADAC_W(7) ADAC_W(8) ADAC_W(9) ADAC_W(10) ADAC_W(11) ADAC_W(12) ADAC_W(13)
 		ADAC_W(14) ADAC_W(15) ADAC_W(16) ADAC_W(17) ADAC_W(18) ADAC_W(19) ADAC_W(20) ADAC_W(21) ADAC_W(22)
 		ADAC_W(23) ADAC_W(24) ADAC_W(25) ADAC_W(26) ADAC_W(27) ADAC_W(28) ADAC_W(29) ADAC_W(30) ADAC_W(31) ADAC_W(32)
@@ -469,6 +482,7 @@ __global__ __launch_bounds__(kWorkgroup) void k_scan_agg(const adac_segment_desc
                                                          const TileRef *__restrict__ tiles, uint32_t ntiles,
                                                          uint32_t group, int templated,
                                                          const uint64_t *__restrict__ words, RangePred pred,
+                                                         const uint64_t *__restrict__ validity,
                                                          uint64_t *__restrict__ result) {
 	constexpr uint32_t TILE = kTileBytes / sizeof(U);
 	__shared__ uint4 lds[kTileBytes / 16 + 2];
@@ -502,8 +516,12 @@ __global__ __launch_bounds__(kWorkgroup) void k_scan_agg(const adac_segment_desc
 			const uint32_t tiles_left = (left + TILE - 1) / TILE;
 			const uint32_t run = tiles_left < hi - t ? tiles_left : hi - t;
 			const uint32_t n = left < run * TILE ? left : run * TILE;
-			scan_run_dispatch<U, OP>(w, reinterpret_cast<const uint4 *>(words + d.word_off), r.first, r.first + n, d,
-			                         pred, acc);
+			const uint4 *seg16 = reinterpret_cast<const uint4 *>(words + d.word_off);
+			if (validity) {
+				scan_run_dispatch<U, OP, true>(w, seg16, r.first, r.first + n, d, pred, validity, acc);
+			} else {
+				scan_run_dispatch<U, OP, false>(w, seg16, r.first, r.first + n, d, pred, validity, acc);
+			}
 			t += run;
 			continue;
 		}
@@ -516,11 +534,13 @@ __global__ __launch_bounds__(kWorkgroup) void k_scan_agg(const adac_segment_desc
 		const uint32_t n = left < run * TILE ? left : run * TILE;
 		const uint32_t bit0 = stage_packed(words + d.word_off, r.first, n, w, lds);
 		__syncthreads();
+		const uint64_t elem0 = d.val_off + r.first;
 		auto sink = [&](int32_t base, const U *vals, bool full) {
 			constexpr int KK = 16 / (int)sizeof(U);
+			const uint32_t vbits = validity ? validity_window(validity, elem0 + (uint32_t)(base < 0 ? 0 : base)) : 0xffffffffu;
 #pragma unroll
 			for (int j = 0; j < KK; j++) {
-				if (full || (uint32_t)(base + j) < n) {
+				if ((full || (uint32_t)(base + j) < n) && ((vbits >> j) & 1u)) {
 					if (OP == 1) {
 						acc += (((uint64_t)vals[j] ^ pred.sbit) - pred.blo) <= pred.bspan ? 1ull : 0ull;
 					} else {
@@ -1012,7 +1032,7 @@ hipError_t launch_fetch(hipStream_t s, uint32_t type_size, const adac_segment_de
 }
 
 hipError_t launch_scan_sum(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs, const TileRef *d_tiles,
-                           uint64_t ntiles, const uint64_t *d_words, uint64_t *d_sums) {
+                           uint64_t ntiles, const uint64_t *d_words, const uint64_t *d_validity, uint64_t *d_sums) {
 	if (ntiles == 0) return hipSuccess;
 	return dispatch_size(type_size, [&](auto tag) {
 		using U = decltype(tag);
@@ -1020,25 +1040,26 @@ hipError_t launch_scan_sum(hipStream_t s, uint32_t type_size, const adac_segment
 		const dim3 grid((unsigned)((ntiles + per - 1) / per));
 		if (g_tuning.scan_probe) { // diagnostic: the scan's loop and loads without the field walk (result meaningless)
 			hipLaunchKernelGGL((k_scan_agg<U, 2>), grid, dim3(kWorkgroup), 0, s, d_descs, d_tiles, (uint32_t)ntiles, per,
-			                   1, d_words, RangePred {}, d_sums);
+			                   1, d_words, RangePred {}, static_cast<const uint64_t *>(nullptr), d_sums);
 			return hipGetLastError();
 		}
 		hipLaunchKernelGGL((k_scan_agg<U, 0>), grid, dim3(kWorkgroup), 0, s, d_descs, d_tiles, (uint32_t)ntiles, per,
-		                   g_tuning.templated_scan, d_words, RangePred {}, d_sums);
+		                   g_tuning.templated_scan, d_words, RangePred {}, d_validity, d_sums);
 		return hipGetLastError();
 	});
 }
 
 hipError_t launch_scan_count_range(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs,
-                                   const TileRef *d_tiles, uint64_t ntiles, const uint64_t *d_words, uint64_t blo,
-                                   uint64_t bspan, uint64_t sbit, uint64_t *d_counts) {
+                                   const TileRef *d_tiles, uint64_t ntiles, const uint64_t *d_words,
+                                   const uint64_t *d_validity, uint64_t blo, uint64_t bspan, uint64_t sbit,
+                                   uint64_t *d_counts) {
 	if (ntiles == 0) return hipSuccess;
 	return dispatch_size(type_size, [&](auto tag) {
 		using U = decltype(tag);
 		const uint32_t per = (uint32_t)g_tuning.scan_tiles_per_wg;
 		hipLaunchKernelGGL((k_scan_agg<U, 1>), dim3((unsigned)((ntiles + per - 1) / per)), dim3(kWorkgroup), 0, s,
 		                   d_descs, d_tiles, (uint32_t)ntiles, per, g_tuning.templated_scan, d_words,
-		                   RangePred {blo, bspan, sbit}, d_counts);
+		                   RangePred {blo, bspan, sbit}, d_validity, d_counts);
 		return hipGetLastError();
 	});
 }

@@ -243,6 +243,13 @@ adac_status adac_scan_count_eq(adac_layout *l, const uint64_t *d_words, uint64_t
 adac_status adac_scan_count_between(adac_layout *l, const uint64_t *d_words, uint64_t lo, uint64_t hi,
                                     uint64_t *d_counts);
 
+/* The same two scans with a DuckDB validity mask over the element index space (bit e of word e/64 set = row e
+ * valid, as for adac_analyze): NULL rows take no part in the aggregate — what SUM / COUNT over a nullable
+ * column mean.  d_validity == NULL is the unmasked scan. */
+adac_status adac_scan_sum_valid(adac_layout *l, const uint64_t *d_words, const uint64_t *d_validity, uint64_t *d_sums);
+adac_status adac_scan_count_between_valid(adac_layout *l, const uint64_t *d_words, const uint64_t *d_validity,
+                                          uint64_t lo, uint64_t hi, uint64_t *d_counts);
+
 /* ---------------------------------------------------------------------------------------------
  * DuckDB BITPACKING segments — the persistent counterpart of the succinct codec, decode side.
  * A segment is the block image DuckDB's checkpoint writes (src/storage/compression/bitpacking.cpp:357-538):

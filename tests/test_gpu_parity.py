@@ -450,3 +450,46 @@ def test_zonemaps(adac, gpu_ctx):
                 assert (zm[s, 0], zm[s, 1]) == (v[ok].min(), v[ok].max()), (dtype, s)
             else:
                 assert zm[s, 0] == info.max and zm[s, 1] == info.min  # empty interval
+
+
+def test_fused_scans_skip_null_rows(adac, oracle, gpu_ctx):
+    """adac_scan_sum_valid / adac_scan_count_between_valid: rows whose validity bit is clear take no part, in
+    both scan forms, at many widths and ragged segment sizes (validity windows straddle mask words)."""
+    rng = np.random.default_rng(61)
+    for dtype, bits_list in ((np.uint64, (5, 13, 32, 47)), (np.int32, (4, 11, 20)), (np.uint16, (7, 12)), (np.uint8, (3, 6))):
+        dtype = np.dtype(dtype)
+        udt = np.dtype("u%d" % dtype.itemsize)
+        tile = adac.tile_values(dtype)
+        counts, segs = [], []
+        for b in bits_list:
+            for n in (int(rng.integers(100, 3 * tile)), 2 * tile, 977):
+                counts.append(n)
+                segs.append(make_values(rng, dtype, n, b))
+        counts = np.array(counts, dtype=np.uint32)
+        lay, d_words, _, descs, _ = run_encode_decode(adac, oracle, gpu_ctx, dtype, counts, segs)
+        total = int(counts.sum())
+        valid = rng.random(total) > 0.35
+        valid[:70] = False
+        vm = np.packbits(valid, bitorder="little")
+        vm = np.concatenate([vm, np.zeros((-len(vm)) % 8 + 8, np.uint8)]).view(np.uint64)
+        d_valid = gpu_ctx.upload(vm)
+        d_res = gpu_ctx.alloc(len(counts) * 8)
+        offs = [int(x) for x in np.concatenate([[0], np.cumsum(counts)[:-1]])]
+        kv = segs[1][5]
+        lo, hi = sorted((int(segs[0][3]), int(segs[0][9])))
+        try:
+            for templated in (1, 0):
+                adac.set_tuning("templated_scan", templated)
+                lay.scan_sum(d_words, d_res, d_valid)
+                got = d_res.download(np.uint64, len(counts)).tolist()
+                exp = [int(v.view(udt)[valid[o:o + len(v)]].astype(np.uint64).sum(dtype=np.uint64)) for v, o in zip(segs, offs)]
+                assert got == exp, (dtype, templated)
+                for a, b in ((kv, kv), (lo, hi)):
+                    ab = int(np.array([a]).astype(dtype).view(udt)[0])
+                    bb = int(np.array([b]).astype(dtype).view(udt)[0])
+                    lay.scan_count_between(d_words, ab, bb, d_res, d_valid)
+                    got = d_res.download(np.uint64, len(counts)).tolist()
+                    exp = [int(((v >= a) & (v <= b) & valid[o:o + len(v)]).sum()) for v, o in zip(segs, offs)]
+                    assert got == exp, (dtype, templated, a, b)
+        finally:
+            adac.set_tuning("templated_scan", 1)
