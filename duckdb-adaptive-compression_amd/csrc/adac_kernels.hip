@@ -374,22 +374,34 @@ struct ChunkAgg {
 	static constexpr bool kFields32 = ((uint64_t)MAXV << W) <= 0xffffffffull; // MAXV fields fit a u32 sum
 	uint32_t p32 = 0;
 	uint64_t p64 = 0;
-	uint32_t nvalid = 0; // rows aggregated (u64 SUM adds nvalid * min at the end)
-	__device__ __forceinline__ void add(uint32_t f, uint32_t add_lo, const FieldRange &fr, bool valid = true) {
-		const uint32_t m = valid ? 0xffffffffu : 0u;
-		nvalid += m & 1u;
+	uint32_t nvalid = 0; // rows aggregated by add_if (u64 SUM adds rows * min at the end)
+	__device__ __forceinline__ void add(uint32_t f, uint32_t add_lo, const FieldRange &fr) {
 		if (OP == 1) {
-			p32 += ((((f ^ fr.fxor) - fr.flo) <= fr.span) ? 1u : 0u) & m; // the predicate, on the packed field
+			p32 += (((f ^ fr.fxor) - fr.flo) <= fr.span) ? 1u : 0u; // the predicate, on the packed field
+		} else if (sizeof(U) == 8) {
+			if (kFields32) p32 += f; else p64 += f;
+		} else if (sizeof(U) == 4) {
+			p64 += (uint32_t)(f + add_lo);
+		} else {
+			p32 += (uint32_t)(U)(f + add_lo); // <= 32 values of <= 16 bits
+		}
+	}
+	__device__ __forceinline__ void add_if(uint32_t f, uint32_t add_lo, const FieldRange &fr, uint32_t valid_bit) {
+		const uint32_t m = 0u - valid_bit;
+		nvalid += valid_bit;
+		if (OP == 1) {
+			p32 += ((((f ^ fr.fxor) - fr.flo) <= fr.span) ? 1u : 0u) & m;
 		} else if (sizeof(U) == 8) {
 			if (kFields32) p32 += f & m; else p64 += f & m;
 		} else if (sizeof(U) == 4) {
 			p64 += (uint32_t)(f + add_lo) & m;
 		} else {
-			p32 += (uint32_t)(U)(f + add_lo) & m; // <= 32 values of <= 16 bits
+			p32 += (uint32_t)(U)(f + add_lo) & m;
 		}
 	}
-	__device__ __forceinline__ uint64_t total(uint64_t add) const {
-		if (OP == 0 && sizeof(U) == 8) return (uint64_t)p32 + p64 + (uint64_t)nvalid * add;
+	// rows: the number of rows aggregated with add(); rows added with add_if() are counted in nvalid
+	__device__ __forceinline__ uint64_t total(uint32_t rows, uint64_t add) const {
+		if (OP == 0 && sizeof(U) == 8) return (uint64_t)p32 + p64 + (uint64_t)(rows + nvalid) * add;
 		return (uint64_t)p32 + p64;
 	}
 };
@@ -445,21 +457,28 @@ __device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint
 		const uint32_t starting = (128u - o0 + (W - 1)) / W; // rows starting in the chunk: MAXV-1 or MAXV
 		const uint32_t lim = r1 > i0 ? r1 - i0 : 0u;
 		ChunkAgg<W, U, OP> agg;
-		// NULL rows (DuckDB validity mask over the element index space) take no part in the aggregate
-		const uint32_t vbits = V ? validity_window(validity, d.val_off + i0) : 0xffffffffu;
-		if (starting <= lim) { // interior chunk: only the last slot may be absent
-#pragma unroll
-			for (int j = 0; j < MAXV - 1; j++) agg.add(field_of<W>(nrm, j), add_lo, fr, !V || ((vbits >> j) & 1u));
-			if (128 % W == 0 || starting == (uint32_t)MAXV) {
-				agg.add(field_of<W>(nrm, MAXV - 1), add_lo, fr, !V || ((vbits >> (MAXV - 1)) & 1u));
-			}
-		} else { // the run ends inside this chunk
+		uint32_t nv = 0;
+		if (V) {
+			// NULL rows (DuckDB validity mask over the element index space) take no part in the aggregate
+			const uint32_t vbits = validity_window(validity, d.val_off + i0);
+			const uint32_t have = starting < lim ? starting : lim;
 #pragma unroll
 			for (int j = 0; j < MAXV; j++) {
-				if ((uint32_t)j < lim) agg.add(field_of<W>(nrm, j), add_lo, fr, !V || ((vbits >> j) & 1u));
+				if ((uint32_t)j < have) agg.add_if(field_of<W>(nrm, j), add_lo, fr, (vbits >> j) & 1u);
+			}
+		} else if (starting <= lim) { // interior chunk: only the last slot may be absent
+			nv = starting;
+#pragma unroll
+			for (int j = 0; j < MAXV - 1; j++) agg.add(field_of<W>(nrm, j), add_lo, fr);
+			if (128 % W == 0 || starting == (uint32_t)MAXV) agg.add(field_of<W>(nrm, MAXV - 1), add_lo, fr);
+		} else { // the run ends inside this chunk
+			nv = lim;
+#pragma unroll
+			for (int j = 0; j < MAXV; j++) {
+				if ((uint32_t)j < nv) agg.add(field_of<W>(nrm, j), add_lo, fr);
 			}
 		}
-		acc += agg.total(add);
+		acc += agg.total(nv, add);
 	}
 }
 
@@ -477,7 +496,7 @@ __device__ __forceinline__ void scan_run_dispatch(uint32_t w, const uint4 *__res
 	}
 }
 
-template <typename U, int OP> // OP 0: SUM, 1: COUNT(lo <= v <= hi), 2: load-only probe
+template <typename U, int OP, bool V> // OP 0: SUM, 1: COUNT(lo <= v <= hi), 2: load-only probe; V: validity mask given
 __global__ __launch_bounds__(kWorkgroup) void k_scan_agg(const adac_segment_desc *__restrict__ descs,
                                                          const TileRef *__restrict__ tiles, uint32_t ntiles,
                                                          uint32_t group, int templated,
@@ -517,11 +536,7 @@ __global__ __launch_bounds__(kWorkgroup) void k_scan_agg(const adac_segment_desc
 			const uint32_t run = tiles_left < hi - t ? tiles_left : hi - t;
 			const uint32_t n = left < run * TILE ? left : run * TILE;
 			const uint4 *seg16 = reinterpret_cast<const uint4 *>(words + d.word_off);
-			if (validity) {
-				scan_run_dispatch<U, OP, true>(w, seg16, r.first, r.first + n, d, pred, validity, acc);
-			} else {
-				scan_run_dispatch<U, OP, false>(w, seg16, r.first, r.first + n, d, pred, validity, acc);
-			}
+			scan_run_dispatch<U, OP, V>(w, seg16, r.first, r.first + n, d, pred, validity, acc);
 			t += run;
 			continue;
 		}
@@ -537,7 +552,7 @@ __global__ __launch_bounds__(kWorkgroup) void k_scan_agg(const adac_segment_desc
 		const uint64_t elem0 = d.val_off + r.first;
 		auto sink = [&](int32_t base, const U *vals, bool full) {
 			constexpr int KK = 16 / (int)sizeof(U);
-			const uint32_t vbits = validity ? validity_window(validity, elem0 + (uint32_t)(base < 0 ? 0 : base)) : 0xffffffffu;
+			const uint32_t vbits = V ? validity_window(validity, elem0 + (uint32_t)(base < 0 ? 0 : base)) : 0xffffffffu;
 #pragma unroll
 			for (int j = 0; j < KK; j++) {
 				if ((full || (uint32_t)(base + j) < n) && ((vbits >> j) & 1u)) {
@@ -1039,12 +1054,17 @@ hipError_t launch_scan_sum(hipStream_t s, uint32_t type_size, const adac_segment
 		const uint32_t per = (uint32_t)g_tuning.scan_tiles_per_wg;
 		const dim3 grid((unsigned)((ntiles + per - 1) / per));
 		if (g_tuning.scan_probe) { // diagnostic: the scan's loop and loads without the field walk (result meaningless)
-			hipLaunchKernelGGL((k_scan_agg<U, 2>), grid, dim3(kWorkgroup), 0, s, d_descs, d_tiles, (uint32_t)ntiles, per,
+			hipLaunchKernelGGL((k_scan_agg<U, 2, false>), grid, dim3(kWorkgroup), 0, s, d_descs, d_tiles, (uint32_t)ntiles, per,
 			                   1, d_words, RangePred {}, static_cast<const uint64_t *>(nullptr), d_sums);
 			return hipGetLastError();
 		}
-		hipLaunchKernelGGL((k_scan_agg<U, 0>), grid, dim3(kWorkgroup), 0, s, d_descs, d_tiles, (uint32_t)ntiles, per,
-		                   g_tuning.templated_scan, d_words, RangePred {}, d_validity, d_sums);
+		if (d_validity) {
+			hipLaunchKernelGGL((k_scan_agg<U, 0, true>), grid, dim3(kWorkgroup), 0, s, d_descs, d_tiles, (uint32_t)ntiles,
+			                   per, g_tuning.templated_scan, d_words, RangePred {}, d_validity, d_sums);
+		} else {
+			hipLaunchKernelGGL((k_scan_agg<U, 0, false>), grid, dim3(kWorkgroup), 0, s, d_descs, d_tiles,
+			                   (uint32_t)ntiles, per, g_tuning.templated_scan, d_words, RangePred {}, d_validity, d_sums);
+		}
 		return hipGetLastError();
 	});
 }
@@ -1057,9 +1077,15 @@ hipError_t launch_scan_count_range(hipStream_t s, uint32_t type_size, const adac
 	return dispatch_size(type_size, [&](auto tag) {
 		using U = decltype(tag);
 		const uint32_t per = (uint32_t)g_tuning.scan_tiles_per_wg;
-		hipLaunchKernelGGL((k_scan_agg<U, 1>), dim3((unsigned)((ntiles + per - 1) / per)), dim3(kWorkgroup), 0, s,
-		                   d_descs, d_tiles, (uint32_t)ntiles, per, g_tuning.templated_scan, d_words,
-		                   RangePred {blo, bspan, sbit}, d_validity, d_counts);
+		const dim3 grid((unsigned)((ntiles + per - 1) / per));
+		const RangePred pred {blo, bspan, sbit};
+		if (d_validity) {
+			hipLaunchKernelGGL((k_scan_agg<U, 1, true>), grid, dim3(kWorkgroup), 0, s, d_descs, d_tiles, (uint32_t)ntiles,
+			                   per, g_tuning.templated_scan, d_words, pred, d_validity, d_counts);
+		} else {
+			hipLaunchKernelGGL((k_scan_agg<U, 1, false>), grid, dim3(kWorkgroup), 0, s, d_descs, d_tiles,
+			                   (uint32_t)ntiles, per, g_tuning.templated_scan, d_words, pred, d_validity, d_counts);
+		}
 		return hipGetLastError();
 	});
 }
