@@ -530,8 +530,9 @@ extern "C" adac_status adac_scan_sum_valid(adac_layout *l, const uint64_t *d_wor
 	if (!aligned16(d_words)) return ADAC_ERR_INVALID_ARGUMENT;
 	ADAC_HIP(hipSetDevice(l->ctx->device));
 	if (l->nseg) ADAC_HIP(hipMemsetAsync(d_sums, 0, l->nseg * sizeof(uint64_t), l->ctx->stream));
+	const uint64_t sbit = l->is_signed ? (1ull << (8 * l->type_size - 1)) : 0ull;
 	ADAC_HIP(adac::launch_scan_sum(l->ctx->stream, l->type_size, l->d_descs, l->d_tiles, l->ntiles, d_words, d_validity,
-	                               d_sums));
+	                               sbit, d_sums));
 	return ADAC_OK;
 }
 

@@ -60,7 +60,7 @@ hipError_t launch_unpack_range(hipStream_t s, uint32_t type_size, const adac_seg
 hipError_t launch_fetch(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs, const uint64_t *d_words,
                         const uint32_t *d_segs, const uint32_t *d_rows, uint64_t n, void *d_out);
 hipError_t launch_scan_sum(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs, const TileRef *d_tiles,
-                           uint64_t ntiles, const uint64_t *d_words, const uint64_t *d_validity, uint64_t *d_sums);
+                           uint64_t ntiles, const uint64_t *d_words, const uint64_t *d_validity, uint64_t sbit, uint64_t *d_sums);
 hipError_t launch_scan_count_range(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs,
                                    const TileRef *d_tiles, uint64_t ntiles, const uint64_t *d_words,
                                    const uint64_t *d_validity, uint64_t blo, uint64_t bspan, uint64_t sbit,

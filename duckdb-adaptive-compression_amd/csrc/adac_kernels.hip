@@ -328,10 +328,9 @@ __device__ __forceinline__ uint32_t field_of(const uint32_t (&nrm)[5], int j) {
 	return __builtin_amdgcn_alignbit(nrm[d + 1], nrm[d], sh) & mask;
 }
 
-// Aggregate the fields of one chunk.  Exactness contract: the result equals aggregating the MATERIALISED
-// values T(field + min) as unsigned T.  For T = u64 that is linear (sum of fields + n*min, mod 2^64); for
-// narrower T the per-element truncation is kept.  Partial sums of a chunk stay in 32-bit registers whenever
-// MAXV fields of W bits cannot overflow them.
+// Aggregate the fields of one chunk.  Exactness contract: SUM equals the sum of the MATERIALISED values, each
+// widened to 64 bits according to T's signedness (what SQL SUM over the column computes), mod 2^64.  Partial
+// sums of a chunk stay in 32-bit registers whenever MAXV fields of W bits cannot overflow them.
 // Range predicate lo <= v <= hi in T's own order (signed for the INT types), through the order-preserving map
 // B(v) = bits(v) ^ sbit:  B(v) - blo <= bspan as unsigned numbers.  `==`, `<`, `<=`, `>`, `>=`, BETWEEN are all
 // instances (column_segment.cpp:575-844 FilterSelection's comparison kinds).
@@ -344,10 +343,36 @@ struct FieldRange {
 	bool any;
 };
 
+// How a segment's stored fields relate to its values in T's own order (signed for the INT types):
+//   SEG_LINEAR   value = min + f without leaving T's range: sums are linear and a range predicate moves into the
+//                field domain.  Every segment the append path packs is linear (its sign-extended min/max order
+//                never packs a mixed-sign range, succinct.cpp:286-287).
+//   SEG_RAW      the stored bits are the value (unpacked slots, or packed without a frame of reference).
+//   SEG_WRAPS    packed with a min, but min + f crosses T's sign boundary: only BitCompressFromUncompressed's
+//                zero-extended order (column_segment.cpp:405-420) can produce it, e.g. {INT_MAX, INT_MIN} -> w = 1.
+//                Such a segment is always decoded to values first (LDS path).
+enum SegKind { SEG_LINEAR, SEG_RAW, SEG_WRAPS };
+
 template <typename U>
-__device__ __forceinline__ FieldRange field_range(const RangePred &p, const adac_segment_desc &d, uint32_t mask) {
+__device__ __forceinline__ SegKind seg_kind(const adac_segment_desc &d, uint64_t sbit) {
+	if (!((d.flags & ADAC_SEG_PACKED) && d.min != ADAC_NO_MIN)) return SEG_RAW;
+	if (sbit == 0) return SEG_LINEAR; // unsigned T: min + f is a stored value, it cannot wrap
+	const uint64_t bmin = (uint64_t)(U)d.min ^ sbit;
+	const uint64_t maxf = d.width >= 64 ? ~0ull : ((1ull << d.width) - 1ull);
+	const uint64_t top = bmin + maxf;
+	return (top >= bmin && top <= (uint64_t)(U)~(U)0) ? SEG_LINEAR : SEG_WRAPS;
+}
+
+// min widened to 64 bits according to T's signedness: with it, value64 = f + add64 on a linear segment
+template <typename U>
+__device__ __forceinline__ uint64_t widened_min(const adac_segment_desc &d, uint64_t sbit) {
+	return ((uint64_t)(U)d.min ^ sbit) - sbit;
+}
+
+template <typename U>
+__device__ __forceinline__ FieldRange field_range(const RangePred &p, const adac_segment_desc &d, uint32_t mask,
+                                                  bool linear) {
 	FieldRange r {0u, 0u, 0u, false};
-	const bool linear = (d.flags & ADAC_SEG_PACKED) && d.min != ADAC_NO_MIN;
 	if (linear) {
 		// v = min + f without wrap in T's order, so B(v) = B(min) + f
 		const uint64_t bmin = (uint64_t)(U)d.min ^ p.sbit;
@@ -375,33 +400,26 @@ struct ChunkAgg {
 	uint32_t p32 = 0;
 	uint64_t p64 = 0;
 	uint32_t nvalid = 0; // rows aggregated by add_if (u64 SUM adds rows * min at the end)
-	__device__ __forceinline__ void add(uint32_t f, uint32_t add_lo, const FieldRange &fr) {
+	__device__ __forceinline__ void add(uint32_t f, const FieldRange &fr) {
 		if (OP == 1) {
 			p32 += (((f ^ fr.fxor) - fr.flo) <= fr.span) ? 1u : 0u; // the predicate, on the packed field
-		} else if (sizeof(U) == 8) {
-			if (kFields32) p32 += f; else p64 += f;
-		} else if (sizeof(U) == 4) {
-			p64 += (uint32_t)(f + add_lo);
 		} else {
-			p32 += (uint32_t)(U)(f + add_lo); // <= 32 values of <= 16 bits
+			if (kFields32) p32 += f; else p64 += f;
 		}
 	}
-	__device__ __forceinline__ void add_if(uint32_t f, uint32_t add_lo, const FieldRange &fr, uint32_t valid_bit) {
+	__device__ __forceinline__ void add_if(uint32_t f, const FieldRange &fr, uint32_t valid_bit) {
 		const uint32_t m = 0u - valid_bit;
 		nvalid += valid_bit;
 		if (OP == 1) {
 			p32 += ((((f ^ fr.fxor) - fr.flo) <= fr.span) ? 1u : 0u) & m;
-		} else if (sizeof(U) == 8) {
-			if (kFields32) p32 += f & m; else p64 += f & m;
-		} else if (sizeof(U) == 4) {
-			p64 += (uint32_t)(f + add_lo) & m;
 		} else {
-			p32 += (uint32_t)(U)(f + add_lo) & m;
+			if (kFields32) p32 += f & m; else p64 += f & m;
 		}
 	}
-	// rows: the number of rows aggregated with add(); rows added with add_if() are counted in nvalid
-	__device__ __forceinline__ uint64_t total(uint32_t rows, uint64_t add) const {
-		if (OP == 0 && sizeof(U) == 8) return (uint64_t)p32 + p64 + (uint64_t)(rows + nvalid) * add;
+	// rows: the number of rows aggregated with add(); rows added with add_if() are counted in nvalid.
+	// SUM is linear on the segments this path takes: sum(value64) = sum(fields) + rows * add64.
+	__device__ __forceinline__ uint64_t total(uint32_t rows, uint64_t add64) const {
+		if (OP == 0) return (uint64_t)p32 + p64 + (uint64_t)(rows + nvalid) * add64;
 		return (uint64_t)p32 + p64;
 	}
 };
@@ -416,18 +434,17 @@ __device__ __forceinline__ uint32_t validity_window(const uint64_t *__restrict__
 
 template <int W, typename U, int OP, bool V>
 __device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint32_t r0, uint32_t r1,
-                                           const adac_segment_desc &d, const RangePred &pred,
+                                           const adac_segment_desc &d, const RangePred &pred, bool linear,
                                            const uint64_t *__restrict__ validity, uint64_t &acc) {
 	constexpr int MAXV = (128 + W - 1) / W;
 	constexpr uint32_t mask = W >= 32 ? 0xffffffffu : ((1u << W) - 1u);
 	const uint32_t c0 = (uint32_t)(((uint64_t)r0 * W) >> 7);       // r0 is a multiple of 128 rows
 	const uint32_t c1 = (uint32_t)(((uint64_t)r1 * W + 127) >> 7);
 	const uint32_t clast = (uint32_t)(((uint64_t)d.count * W + 127) >> 7) - 1; // last chunk holding data bits
-	const uint64_t add = effective_add(d);
-	const uint32_t add_lo = (uint32_t)add;
+	const uint64_t add = linear ? widened_min<U>(d, pred.sbit) : 0ull;
 	FieldRange fr {0u, 0u, 0u, true};
 	if (OP == 1) {
-		fr = field_range<U>(pred, d, mask);
+		fr = field_range<U>(pred, d, mask, linear);
 		if (!fr.any) return; // zonemap-style skip: no row of this segment can satisfy the predicate
 	}
 	// software pipeline: the next chunk's loads are issued (unconditionally, index clamped into the segment)
@@ -464,18 +481,18 @@ __device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint
 			const uint32_t have = starting < lim ? starting : lim;
 #pragma unroll
 			for (int j = 0; j < MAXV; j++) {
-				if ((uint32_t)j < have) agg.add_if(field_of<W>(nrm, j), add_lo, fr, (vbits >> j) & 1u);
+				if ((uint32_t)j < have) agg.add_if(field_of<W>(nrm, j), fr, (vbits >> j) & 1u);
 			}
 		} else if (starting <= lim) { // interior chunk: only the last slot may be absent
 			nv = starting;
 #pragma unroll
-			for (int j = 0; j < MAXV - 1; j++) agg.add(field_of<W>(nrm, j), add_lo, fr);
-			if (128 % W == 0 || starting == (uint32_t)MAXV) agg.add(field_of<W>(nrm, MAXV - 1), add_lo, fr);
+			for (int j = 0; j < MAXV - 1; j++) agg.add(field_of<W>(nrm, j), fr);
+			if (128 % W == 0 || starting == (uint32_t)MAXV) agg.add(field_of<W>(nrm, MAXV - 1), fr);
 		} else { // the run ends inside this chunk
 			nv = lim;
 #pragma unroll
 			for (int j = 0; j < MAXV; j++) {
-				if ((uint32_t)j < nv) agg.add(field_of<W>(nrm, j), add_lo, fr);
+				if ((uint32_t)j < nv) agg.add(field_of<W>(nrm, j), fr);
 			}
 		}
 		acc += agg.total(nv, add);
@@ -485,9 +502,9 @@ __device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint
 template <typename U, int OP, bool V>
 __device__ __forceinline__ void scan_run_dispatch(uint32_t w, const uint4 *__restrict__ seg16, uint32_t r0,
                                                   uint32_t r1, const adac_segment_desc &d, const RangePred &pred,
-                                                  const uint64_t *__restrict__ validity, uint64_t &acc) {
+                                                  bool linear, const uint64_t *__restrict__ validity, uint64_t &acc) {
 	switch (w) {
-#define ADAC_W(N) case N: scan_run_w<N, U, OP, V>(seg16, r0, r1, d, pred, validity, acc); break;
+#define ADAC_W(N) case N: scan_run_w<N, U, OP, V>(seg16, r0, r1, d, pred, linear, validity, acc); break;
 		ADAC_W(4) ADAC_W(5) ADAC_W(6) ADAC_W(7) ADAC_W(8) ADAC_W(9) ADAC_W(10) ADAC_W(11) ADAC_W(12) ADAC_W(13)
 		ADAC_W(14) ADAC_W(15) ADAC_W(16) ADAC_W(17) ADAC_W(18) ADAC_W(19) ADAC_W(20) ADAC_W(21) ADAC_W(22)
 		ADAC_W(23) ADAC_W(24) ADAC_W(25) ADAC_W(26) ADAC_W(27) ADAC_W(28) ADAC_W(29) ADAC_W(30) ADAC_W(31) ADAC_W(32)
@@ -525,9 +542,11 @@ __global__ __launch_bounds__(kWorkgroup) void k_scan_agg(const adac_segment_desc
 		}
 		const adac_segment_desc d = descs[r.seg];
 		const uint32_t w = d.width;
-		const bool linear = (d.flags & ADAC_SEG_PACKED) && d.min != ADAC_NO_MIN;
-		if (templated && w >= 4 && w <= 32 && (uint64_t)d.count * w < (1ull << 31) &&
-		    (OP != 1 || linear || sizeof(U) <= 4)) {
+		const SegKind kind = seg_kind<U>(d, pred.sbit);
+		// the register path works on fields: linear segments, and raw ones whose field IS the value it needs
+		// (SUM: unsigned T; COUNT: any T the 32-bit field holds whole)
+		const bool by_field = kind == SEG_LINEAR || (kind == SEG_RAW && (OP == 1 ? sizeof(U) <= 4 : pred.sbit == 0));
+		if (templated && w >= 4 && w <= 32 && (uint64_t)d.count * w < (1ull << 31) && by_field) {
 			// width-templated register path: the whole run of this segment's tiles in this group, no LDS
 			// tiles of one segment are consecutive table entries, so the run length is arithmetic (walking the
 			// table entry by entry costs one dependent scalar load per tile: measured 3.0 -> TB/s-bound)
@@ -536,7 +555,7 @@ __global__ __launch_bounds__(kWorkgroup) void k_scan_agg(const adac_segment_desc
 			const uint32_t run = tiles_left < hi - t ? tiles_left : hi - t;
 			const uint32_t n = left < run * TILE ? left : run * TILE;
 			const uint4 *seg16 = reinterpret_cast<const uint4 *>(words + d.word_off);
-			scan_run_dispatch<U, OP, V>(w, seg16, r.first, r.first + n, d, pred, validity, acc);
+			scan_run_dispatch<U, OP, V>(w, seg16, r.first, r.first + n, d, pred, kind == SEG_LINEAR, validity, acc);
 			t += run;
 			continue;
 		}
@@ -559,7 +578,7 @@ __global__ __launch_bounds__(kWorkgroup) void k_scan_agg(const adac_segment_desc
 					if (OP == 1) {
 						acc += (((uint64_t)vals[j] ^ pred.sbit) - pred.blo) <= pred.bspan ? 1ull : 0ull;
 					} else {
-						acc += (uint64_t)vals[j];
+						acc += ((uint64_t)vals[j] ^ pred.sbit) - pred.sbit; // widened by T's signedness
 					}
 				}
 			}
@@ -1047,8 +1066,10 @@ hipError_t launch_fetch(hipStream_t s, uint32_t type_size, const adac_segment_de
 }
 
 hipError_t launch_scan_sum(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs, const TileRef *d_tiles,
-                           uint64_t ntiles, const uint64_t *d_words, const uint64_t *d_validity, uint64_t *d_sums) {
+                           uint64_t ntiles, const uint64_t *d_words, const uint64_t *d_validity, uint64_t sbit,
+                           uint64_t *d_sums) {
 	if (ntiles == 0) return hipSuccess;
+	const RangePred widen {0ull, 0ull, sbit}; // SUM only needs T's sign bit
 	return dispatch_size(type_size, [&](auto tag) {
 		using U = decltype(tag);
 		const uint32_t per = (uint32_t)g_tuning.scan_tiles_per_wg;
@@ -1060,10 +1081,10 @@ hipError_t launch_scan_sum(hipStream_t s, uint32_t type_size, const adac_segment
 		}
 		if (d_validity) {
 			hipLaunchKernelGGL((k_scan_agg<U, 0, true>), grid, dim3(kWorkgroup), 0, s, d_descs, d_tiles, (uint32_t)ntiles,
-			                   per, g_tuning.templated_scan, d_words, RangePred {}, d_validity, d_sums);
+			                   per, g_tuning.templated_scan, d_words, widen, d_validity, d_sums);
 		} else {
 			hipLaunchKernelGGL((k_scan_agg<U, 0, false>), grid, dim3(kWorkgroup), 0, s, d_descs, d_tiles,
-			                   (uint32_t)ntiles, per, g_tuning.templated_scan, d_words, RangePred {}, d_validity, d_sums);
+			                   (uint32_t)ntiles, per, g_tuning.templated_scan, d_words, widen, d_validity, d_sums);
 		}
 		return hipGetLastError();
 	});

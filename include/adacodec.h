@@ -226,8 +226,9 @@ adac_status adac_unpack_range(adac_layout *l, const uint64_t *d_words, uint64_t 
 adac_status adac_fetch_rows(adac_layout *l, const uint64_t *d_words, const uint32_t *d_segs, const uint32_t *d_rows,
                             uint64_t n, void *d_out);
 
-/* Fused scan + aggregate without materialising: d_sums[seg] = sum of decoded values (as unsigned T) mod 2^64.
- * (what a SUM over a succinct column needs; reads packed bytes only.) */
+/* Fused scan + aggregate without materialising: d_sums[seg] = sum of the decoded values, each widened to 64 bits
+ * according to T's signedness (sign-extended for the INT types, zero-extended for the UINT types), mod 2^64 —
+ * the low 64 bits of SQL SUM over the segment.  (reads packed bytes only.) */
 adac_status adac_scan_sum(adac_layout *l, const uint64_t *d_words, uint64_t *d_sums);
 
 /* Fused scan + equality filter: d_counts[seg] = number of rows whose decoded value == key (key given as the

@@ -92,7 +92,7 @@ def test_c3_tpch_sf10_lineitem_integer_columns(adac, gpu_ctx):
         assert np.array_equal(d_out.download(np.int32, n), v), name
         d_res = gpu_ctx.alloc(len(counts) * 8)
         lay.scan_sum(d_words, d_res)  # Q1/Q6-style SUM over the packed column
-        assert int(d_res.download(np.uint64, len(counts)).sum(dtype=np.uint64)) == int(v.astype(np.uint64).sum())
+        assert int(d_res.download(np.uint64, len(counts)).sum(dtype=np.uint64)) == int(v.astype(np.int64).sum()) & 0xFFFFFFFFFFFFFFFF
         if name == "l_quantity":      # Q6-style predicate count on the packed column
             lay.scan_count_eq(d_words, 24, d_res)
             assert int(d_res.download(np.uint64, len(counts)).sum()) == int((v == 24).sum())

@@ -44,6 +44,12 @@ def oracle_encode(orc, seg_vals, rule, padded, validity=None, val_offs=None):
     return out
 
 
+def wide_sum(v):
+    """What adac_scan_sum reports: the values widened to 64 bits by T's signedness, summed mod 2^64."""
+    wide = np.int64 if v.dtype.kind == "i" else np.uint64
+    return int(v.astype(wide).sum(dtype=wide)) & 0xFFFFFFFFFFFFFFFF
+
+
 def run_encode_decode(adac, orc, ctx, dtype, counts, seg_vals, rule=0, padded=False, validity=None, val_offs=None):
     dtype = np.dtype(dtype)
     lay = adac.Layout(ctx, dtype, counts, val_offs)
@@ -126,7 +132,7 @@ def test_every_width(adac, oracle, gpu_ctx, dtype):
     assert widths[tb - 1] == tb and not (descs["flags"][tb - 1] & adac.SEG_PACKED)
     # the fused scans at every width, in both kernel forms (width-templated registers / LDS image)
     udt = np.dtype("u%d" % np.dtype(dtype).itemsize)
-    exp_sum = [int(v.view(udt).astype(np.uint64).sum(dtype=np.uint64)) for v in seg_vals]
+    exp_sum = [wide_sum(v) for v in seg_vals]
     keys = [seg_vals[5][3], seg_vals[tb // 2][0]]
     d_res = gpu_ctx.alloc(len(counts) * 8)
     try:
@@ -323,7 +329,7 @@ def test_fused_scan_aggregates(adac, oracle, gpu_ctx):
         lay.scan_sum(d_words, d_res)
         sums = d_res.download(np.uint64, len(counts))
         udt = np.dtype("u%d" % dtype.itemsize)
-        exp = [int(v.view(udt).astype(np.uint64).sum(dtype=np.uint64)) for v in seg_vals]
+        exp = [wide_sum(v) for v in seg_vals]
         assert sums.tolist() == exp
         key_val = seg_vals[0][17]
         key = int(np.array([key_val]).view(udt)[0])
@@ -359,8 +365,7 @@ def test_large_single_segments(adac, oracle, gpu_ctx):
         d_res = gpu_ctx.alloc(len(counts) * 8)
         lay.scan_sum(d_words, d_res)
         udt = np.dtype("u%d" % dtype.itemsize)
-        assert d_res.download(np.uint64, 3).tolist() == \
-            [int(v.view(udt).astype(np.uint64).sum(dtype=np.uint64)) for v in seg_vals]
+        assert d_res.download(np.uint64, 3).tolist() == [wide_sum(v) for v in seg_vals]
         kv = seg_vals[0][n - 2]
         lay.scan_count_eq(d_words, int(np.array([kv]).view(udt)[0]), d_res)
         assert d_res.download(np.uint64, 3).tolist() == [int((v == kv).sum()) for v in seg_vals]
@@ -482,7 +487,7 @@ def test_fused_scans_skip_null_rows(adac, oracle, gpu_ctx):
                 adac.set_tuning("templated_scan", templated)
                 lay.scan_sum(d_words, d_res, d_valid)
                 got = d_res.download(np.uint64, len(counts)).tolist()
-                exp = [int(v.view(udt)[valid[o:o + len(v)]].astype(np.uint64).sum(dtype=np.uint64)) for v, o in zip(segs, offs)]
+                exp = [wide_sum(v[valid[o:o + len(v)]]) for v, o in zip(segs, offs)]
                 assert got == exp, (dtype, templated)
                 for a, b in ((kv, kv), (lo, hi)):
                     ab = int(np.array([a]).astype(dtype).view(udt)[0])
@@ -491,5 +496,45 @@ def test_fused_scans_skip_null_rows(adac, oracle, gpu_ctx):
                     got = d_res.download(np.uint64, len(counts)).tolist()
                     exp = [int(((v >= a) & (v <= b) & valid[o:o + len(v)]).sum()) for v, o in zip(segs, offs)]
                     assert got == exp, (dtype, templated, a, b)
+        finally:
+            adac.set_tuning("templated_scan", 1)
+
+
+def test_scans_on_segments_crossing_the_sign_boundary(adac, oracle, gpu_ctx):
+    """BitCompressFromUncompressed orders values ZERO-extended (column_segment.cpp:405-420), so a signed segment
+    such as {INT_MAX, INT_MIN} packs at w = 1 although min + field leaves T's signed range.  Fused scans must
+    not treat such a segment as linear; all-negative and all-positive ones are."""
+    rng = np.random.default_rng(77)
+    for dtype in (np.int8, np.int16, np.int32, np.int64):
+        dtype = np.dtype(dtype)
+        info = np.iinfo(dtype)
+        n = 50_000
+        span = 200 if dtype.itemsize > 1 else 60
+        udt = np.dtype("u%d" % dtype.itemsize)
+        cross = ((np.uint64(info.max - span // 2) + rng.integers(0, span, size=n).astype(np.uint64))
+                 & np.uint64((1 << (8 * dtype.itemsize)) - 1)).astype(udt).view(dtype)  # INT_MAX-ish .. INT_MIN-ish
+        cross[0], cross[1] = info.max, info.min
+        neg = rng.integers(-100, -3, size=n).astype(dtype)
+        pos = rng.integers(5, 120, size=n).astype(dtype)
+        edge = np.array([info.max, info.min], dtype=dtype)
+        segs = [cross, neg, pos, edge]
+        counts = np.array([len(v) for v in segs], dtype=np.uint32)
+        lay, d_words, _, descs, _ = run_encode_decode(adac, oracle, gpu_ctx, dtype, counts, segs, adac.RULE_RECOMPACT)
+        assert all(descs["flags"] & adac.SEG_PACKED) and int(descs["width"][3]) == 1
+        assert (cross < 0).any() and (cross > 0).any()
+        d_res = gpu_ctx.alloc(len(counts) * 8)
+        try:
+            for templated in (1, 0):
+                adac.set_tuning("templated_scan", templated)
+                lay.scan_sum(d_words, d_res)
+                assert d_res.download(np.uint64, len(counts)).tolist() == [wide_sum(v) for v in segs], (dtype, templated)
+                probes = [(info.min, info.min + 50), (info.max - 40, info.max), (-50, 50), (info.min, info.max),
+                          (-100, -3), (int(info.max), int(info.max)), (int(info.min), int(info.min))]
+                for a, b in probes:
+                    ab = int(np.array([a]).astype(dtype).view(udt)[0])
+                    bb = int(np.array([b]).astype(dtype).view(udt)[0])
+                    lay.scan_count_between(d_words, ab, bb, d_res)
+                    exp = [int(((v >= a) & (v <= b)).sum()) for v in segs]
+                    assert d_res.download(np.uint64, len(counts)).tolist() == exp, (dtype, templated, a, b)
         finally:
             adac.set_tuning("templated_scan", 1)
