@@ -163,7 +163,13 @@ def run_sweep(adac, torch, ctx, base_rows, steps):
             torch.cuda.synchronize()
             col.layout.scan_sum(col.d_words, d_sums)
             ms_sum = time_launches(ctx, lambda: col.layout.scan_sum(col.d_words, d_sums), steps)
+            d_bm = torch.zeros((rows + 63) // 64 + 1, dtype=torch.int64, device="cuda:%d" % ctx.device)
+            torch.cuda.synchronize()
+            sel = lambda: col.layout.scan_select_between(col.d_words, 0, 2 ** (w - 1), d_bm, d_sums)
+            sel()
+            ms_sel = time_launches(ctx, sel, steps)
             out.append({
+                "select_read_GBps": rd / (ms_sel * 1e-3) / 1e9,
                 "dtype": "u%d" % (8 * dtype.itemsize), "width": w, "rows": rows,
                 "widths_seen": sorted(set(descs["width"].tolist())),
                 "decode_values_per_s": rows / (ms * 1e-3),
@@ -173,7 +179,7 @@ def run_sweep(adac, torch, ctx, base_rows, steps):
                 "fused_sum_read_GBps": rd / (ms_sum * 1e-3) / 1e9,
                 "fused_sum_read_frac_of_peak": rd / (ms_sum * 1e-3) / 1e9 / HBM_PEAK_GBS,
             })
-            del col, d_sums
+            del col, d_sums, d_bm
             torch.cuda.empty_cache()
     return out
 
@@ -347,6 +353,22 @@ def main():
             "kernel": "k_scan_agg<u64,sum>", "values_per_s": args.rows / (ms_sum * 1e-3),
             "read_GBps": rd / (ms_sum * 1e-3) / 1e9, "read_frac_of_peak": rd / (ms_sum * 1e-3) / 1e9 / HBM_PEAK_GBS,
         }
+        # filter scan with a selection-bitmap result (FilterSelection on packed bytes): value <= median
+        d_bm = torch.zeros((args.rows + 63) // 64 + 1, dtype=torch.int64, device=col.d_vals.device)
+        median = int(np.median(vals[:1_000_000]))
+        torch.cuda.synchronize()
+        sel = lambda: col.layout.scan_select_between(col.d_words, 0, median, d_bm, d_sums)
+        sel()
+        ctx.sync()
+        if int(d_sums.sum().item()) != int((vals <= median).sum()):
+            raise RuntimeError("parity failure: selection count")
+        ms_sel = time_launches(ctx, sel, args.steps)
+        result["fused_scan"]["select_bitmap"] = {
+            "kernel": "k_scan_agg<u64,select>", "values_per_s": args.rows / (ms_sel * 1e-3), "ms": ms_sel,
+            "read_GBps": rd / (ms_sel * 1e-3) / 1e9, "bitmap_bytes": (args.rows + 7) // 8,
+            "note": "includes clearing the bitmap (hipMemsetAsync) before the kernel",
+        }
+        del d_bm
         # measured device copy rate, for "fraction of achievable" next to "fraction of spec peak"
         src = col.d_vals
         dst = torch.empty_like(src)

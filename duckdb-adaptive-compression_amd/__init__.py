@@ -127,6 +127,7 @@ SIGNATURES = {
     "adac_scan_count_eq": (_int, [_vp, _vp, _u64, _vp]),
     "adac_scan_count_between": (_int, [_vp, _vp, _u64, _u64, _vp]),
     "adac_scan_sum_valid": (_int, [_vp, _vp, _vp, _vp]),
+    "adac_scan_select_between": (_int, [_vp, _vp, _vp, _u64, _u64, _vp, _vp]),
     "adac_scan_count_between_valid": (_int, [_vp, _vp, _vp, _u64, _u64, _vp]),
     "adac_bp_layout_create": (_int, [_vp, _int, _vp, _vp, _vp, _u64, _P(_vp)]),
     "adac_bp_layout_destroy": (None, [_vp]),
@@ -394,6 +395,11 @@ class Layout:
         """lo / hi: bit patterns of the column type (use int(np.array([v], dtype).view(unsigned)[0]) for signed)."""
         _check(lib().adac_scan_count_between_valid(self._h, _dptr(d_words), _dptr(d_validity), lo & NO_MIN, hi & NO_MIN,
                                                    _dptr(d_counts)), "adac_scan_count_between")
+
+    def scan_select_between(self, d_words, lo, hi, d_bitmap, d_counts, d_validity=None):
+        """Selection bitmap over the element index space (ceil(value_span / 64) words) + per-segment hit counts."""
+        _check(lib().adac_scan_select_between(self._h, _dptr(d_words), _dptr(d_validity), lo & NO_MIN, hi & NO_MIN,
+                                              _dptr(d_bitmap), _dptr(d_counts)), "adac_scan_select_between")
 
     def scan_count_eq(self, d_words, key, d_counts):
         _check(lib().adac_scan_count_eq(self._h, _dptr(d_words), key & NO_MIN, _dptr(d_counts)), "adac_scan_count_eq")

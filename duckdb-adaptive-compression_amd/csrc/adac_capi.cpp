@@ -544,22 +544,36 @@ extern "C" adac_status adac_scan_count_between(adac_layout *l, const uint64_t *d
 	return adac_scan_count_between_valid(l, d_words, nullptr, lo, hi, d_counts);
 }
 
-extern "C" adac_status adac_scan_count_between_valid(adac_layout *l, const uint64_t *d_words,
-                                                     const uint64_t *d_validity, uint64_t lo, uint64_t hi,
-                                                     uint64_t *d_counts) {
+static adac_status scan_range(adac_layout *l, const uint64_t *d_words, const uint64_t *d_validity, uint64_t lo,
+                              uint64_t hi, uint64_t *d_counts, uint64_t *d_bitmap, bool want_bitmap) {
 	if (!l || (l->nseg && !d_counts) || (l->total_values && !d_words)) return ADAC_ERR_INVALID_ARGUMENT;
+	if (want_bitmap && ((l->value_span && !d_bitmap) || d_bitmap == d_validity)) return ADAC_ERR_INVALID_ARGUMENT;
 	if (!aligned16(d_words)) return ADAC_ERR_INVALID_ARGUMENT;
 	ADAC_HIP(hipSetDevice(l->ctx->device));
 	if (l->nseg) ADAC_HIP(hipMemsetAsync(d_counts, 0, l->nseg * sizeof(uint64_t), l->ctx->stream));
+	if (want_bitmap && l->value_span) { // edge words are OR-ed in: the bitmap starts clear
+		ADAC_HIP(hipMemsetAsync(d_bitmap, 0, ((l->value_span + 63) / 64) * sizeof(uint64_t), l->ctx->stream));
+	}
 	// order-preserving map of T onto unsigned numbers: flip the sign bit of the signed types
 	const uint32_t bits = 8 * l->type_size;
 	const uint64_t umask = bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);
 	const uint64_t sbit = l->is_signed ? (1ull << (bits - 1)) : 0ull;
 	const uint64_t blo = (lo & umask) ^ sbit, bhi = (hi & umask) ^ sbit;
-	if (bhi < blo) return ADAC_OK; // empty range: all counts stay zero
+	if (bhi < blo) return ADAC_OK; // empty range: all counts (and bits) stay zero
 	ADAC_HIP(adac::launch_scan_count_range(l->ctx->stream, l->type_size, l->d_descs, l->d_tiles, l->ntiles, d_words,
-	                                       d_validity, blo, bhi - blo, sbit, d_counts));
+	                                       d_validity, blo, bhi - blo, sbit, d_counts, want_bitmap ? d_bitmap : nullptr));
 	return ADAC_OK;
+}
+
+extern "C" adac_status adac_scan_count_between_valid(adac_layout *l, const uint64_t *d_words,
+                                                     const uint64_t *d_validity, uint64_t lo, uint64_t hi,
+                                                     uint64_t *d_counts) {
+	return scan_range(l, d_words, d_validity, lo, hi, d_counts, nullptr, false);
+}
+
+extern "C" adac_status adac_scan_select_between(adac_layout *l, const uint64_t *d_words, const uint64_t *d_validity,
+                                                uint64_t lo, uint64_t hi, uint64_t *d_bitmap, uint64_t *d_counts) {
+	return scan_range(l, d_words, d_validity, lo, hi, d_counts, d_bitmap, true);
 }
 
 extern "C" adac_status adac_scan_count_eq(adac_layout *l, const uint64_t *d_words, uint64_t key, uint64_t *d_counts) {

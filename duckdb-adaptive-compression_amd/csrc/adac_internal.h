@@ -64,7 +64,7 @@ hipError_t launch_scan_sum(hipStream_t s, uint32_t type_size, const adac_segment
 hipError_t launch_scan_count_range(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs,
                                    const TileRef *d_tiles, uint64_t ntiles, const uint64_t *d_words,
                                    const uint64_t *d_validity, uint64_t blo, uint64_t bspan, uint64_t sbit,
-                                   uint64_t *d_counts);
+                                   uint64_t *d_counts, uint64_t *d_bitmap);
 
 // DuckDB BITPACKING segments (adac_bitpacking.inl).  Host view of one metadata group; must match BpGroup.
 struct BpGroupHost {

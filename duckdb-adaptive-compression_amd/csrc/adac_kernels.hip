@@ -294,7 +294,7 @@ __device__ __forceinline__ void decode_run(const uint32_t *lds32, uint32_t bit0,
 	uint32_t bit = bit0 + __umul24(threadIdx.x * K, w);
 	const uint32_t step = PER_ROUND * w;
 	const uint32_t rounds = n / PER_ROUND;
-#pragma unroll 4
+#pragma unroll 1
 	for (uint32_t r = 0; r < rounds; r++) {
 		U vals[K];
 #pragma unroll
@@ -328,6 +328,49 @@ __device__ __forceinline__ uint32_t field_of(const uint32_t (&nrm)[5], int j) {
 	return __builtin_amdgcn_alignbit(nrm[d + 1], nrm[d], sh) & mask;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Selection-bitmap output of the filter scan (OP 3).  The lanes of a wave hold selection bits for ASCENDING,
+// adjacent element ranges (a lane's rows follow the previous lane's), together [E0, E1).  Each lane ORs its bits
+// into the wave's private LDS words (ds_or_b32); the wave then writes every 32-bit bitmap word that lies wholly
+// inside [E0, E1) with a plain coalesced store — no other wave owns a bit of it — and only the two edge words
+// with a global atomicOr (the bitmap is zeroed before the launch).  One wave's DS operations execute in order,
+// so no barrier is needed; the words are left zero for the next call.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSelWordsPerWave = 4 * 64 + 4; // register path: 4 iterations x (64 lanes x <= 32 rows) + straddle
+struct SelOut {
+	uint32_t *wave_words; // this wave's kSelWordsPerWave LDS words, zero on entry
+	uint32_t *bitmap32;   // the output bitmap viewed as little-endian 32-bit words
+};
+
+__device__ __forceinline__ void wave_emit_bits(const SelOut &o, uint64_t e0, uint32_t bits, uint32_t nbits) {
+	const uint64_t exec = __builtin_amdgcn_ballot_w64(true);
+	const uint32_t nact = (uint32_t)__popcll(exec);
+	const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(exec >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)exec, 0u));
+	const int first = __ffsll((unsigned long long)exec) - 1;
+	const int last = 63 - __clzll((long long)exec);
+	const uint64_t E0 = __shfl(e0, first, 64);
+	const uint64_t E1 = __shfl(e0 + nbits, last, 64);
+	const uint64_t base = E0 & ~31ull;
+	const uint32_t rel = (uint32_t)(e0 - base), sh = rel & 31u, idx = rel >> 5;
+	if (bits) {
+		atomicOr(&o.wave_words[idx], bits << sh);
+		if (sh + nbits > 32u) atomicOr(&o.wave_words[idx + 1], bits >> (32u - sh));
+	}
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	const uint32_t nwords = ((uint32_t)(E1 - base) + 31u) >> 5;
+	for (uint32_t i = rank; i < nwords; i += nact) {
+		const uint32_t v = atomicExch(&o.wave_words[i], 0u);
+		const uint64_t wb = base + 32ull * i;
+		uint32_t *g = o.bitmap32 + (wb >> 5);
+		if (wb >= E0 && wb + 32u <= E1) {
+			*g = v;
+		} else if (v) {
+			atomicOr(g, v);
+		}
+	}
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Aggregate the fields of one chunk.  Exactness contract: SUM equals the sum of the MATERIALISED values, each
 // widened to 64 bits according to T's signedness (what SQL SUM over the column computes), mod 2^64.  Partial
 // sums of a chunk stay in 32-bit registers whenever MAXV fields of W bits cannot overflow them.
@@ -337,9 +380,9 @@ __device__ __forceinline__ uint32_t field_of(const uint32_t (&nrm)[5], int j) {
 struct RangePred {
 	uint64_t blo, bspan, sbit;
 };
-// The same predicate moved into the packed-field domain of one segment: ((f ^ fxor) - flo) <= span.
+// The same predicate moved into the packed-field domain of one segment: (f - flo) <= span in 32-bit arithmetic.
 struct FieldRange {
-	uint32_t fxor, flo, span;
+	uint32_t flo, span;
 	bool any;
 };
 
@@ -372,7 +415,7 @@ __device__ __forceinline__ uint64_t widened_min(const adac_segment_desc &d, uint
 template <typename U>
 __device__ __forceinline__ FieldRange field_range(const RangePred &p, const adac_segment_desc &d, uint32_t mask,
                                                   bool linear) {
-	FieldRange r {0u, 0u, 0u, false};
+	FieldRange r {0u, 0u, false};
 	if (linear) {
 		// v = min + f without wrap in T's order, so B(v) = B(min) + f
 		const uint64_t bmin = (uint64_t)(U)d.min ^ p.sbit;
@@ -384,43 +427,34 @@ __device__ __forceinline__ FieldRange field_range(const RangePred &p, const adac
 		r.flo = (uint32_t)flo;
 		r.span = (uint32_t)(fhi - flo);
 	} else {
-		// the stored bits are the value (unpacked slots, or a segment without a frame of reference)
-		r.fxor = (uint32_t)p.sbit;
-		r.flo = (uint32_t)p.blo;
+		// the stored bits are the value (unpacked slots, or a segment without a frame of reference): unsigned T,
+		// or a 32-bit signed T, where B(v) = f ^ 2^31 = f + 2^31 (mod 2^32) folds into the lower bound
+		r.flo = (uint32_t)p.blo - (uint32_t)p.sbit;
 		r.span = (uint32_t)p.bspan;
 	}
 	r.any = true;
 	return r;
 }
 
-template <int W, typename U, int OP>
-struct ChunkAgg {
+template <int W>
+struct ChunkSum {
 	static constexpr int MAXV = (128 + W - 1) / W;
 	static constexpr bool kFields32 = ((uint64_t)MAXV << W) <= 0xffffffffull; // MAXV fields fit a u32 sum
 	uint32_t p32 = 0;
 	uint64_t p64 = 0;
-	uint32_t nvalid = 0; // rows aggregated by add_if (u64 SUM adds rows * min at the end)
-	__device__ __forceinline__ void add(uint32_t f, const FieldRange &fr) {
-		if (OP == 1) {
-			p32 += (((f ^ fr.fxor) - fr.flo) <= fr.span) ? 1u : 0u; // the predicate, on the packed field
-		} else {
-			if (kFields32) p32 += f; else p64 += f;
-		}
+	uint32_t nvalid = 0; // rows aggregated by add_if
+	__device__ __forceinline__ void add(uint32_t f) {
+		if (kFields32) p32 += f; else p64 += f;
 	}
-	__device__ __forceinline__ void add_if(uint32_t f, const FieldRange &fr, uint32_t valid_bit) {
+	__device__ __forceinline__ void add_if(uint32_t f, uint32_t valid_bit) {
 		const uint32_t m = 0u - valid_bit;
 		nvalid += valid_bit;
-		if (OP == 1) {
-			p32 += ((((f ^ fr.fxor) - fr.flo) <= fr.span) ? 1u : 0u) & m;
-		} else {
-			if (kFields32) p32 += f & m; else p64 += f & m;
-		}
+		if (kFields32) p32 += f & m; else p64 += f & m;
 	}
 	// rows: the number of rows aggregated with add(); rows added with add_if() are counted in nvalid.
 	// SUM is linear on the segments this path takes: sum(value64) = sum(fields) + rows * add64.
 	__device__ __forceinline__ uint64_t total(uint32_t rows, uint64_t add64) const {
-		if (OP == 0) return (uint64_t)p32 + p64 + (uint64_t)(rows + nvalid) * add64;
-		return (uint64_t)p32 + p64;
+		return (uint64_t)p32 + p64 + (uint64_t)(rows + nvalid) * add64;
 	}
 };
 
@@ -432,29 +466,83 @@ __device__ __forceinline__ uint32_t validity_window(const uint64_t *__restrict__
 	return (uint32_t)wnd;
 }
 
+// Register-path form of the selection output.  Here a WAVE owns a contiguous quarter of the run's chunks, so the
+// rows of its successive iterations are adjacent: it ORs the hit bits of kSelBlock iterations into its LDS image
+// and only then writes the image out (lane i owns words i, i + 64, ...): whole words with plain coalesced
+// stores, the two edge words with atomicOr.  All positions are 32-bit offsets `p = (val_off & 31) + row` from
+// the bitmap word holding the segment's first element; [p0, p1) is what the wave covered since the last flush.
+constexpr uint32_t kSelBlock = 4;                                  // iterations per flush
+static_assert(kSelWordsPerWave >= (int)kSelBlock * 64 + 4, "LDS image of a wave");
+
+__device__ __forceinline__ void sel_or(const SelOut &o, uint32_t p_base, uint32_t p, uint32_t bits, uint32_t nbits) {
+	if (bits) {
+		const uint32_t rel = p - p_base, sh = rel & 31u, idx = rel >> 5;
+		atomicOr(&o.wave_words[idx], bits << sh);
+		if (sh + nbits > 32u) atomicOr(&o.wave_words[idx + 1], bits >> (32u - sh));
+	}
+}
+
+__device__ __forceinline__ void sel_flush(const SelOut &o, uint32_t *__restrict__ seg_words32, uint32_t p0, uint32_t p1) {
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	const uint32_t base = p0 & ~31u;
+	const uint32_t nwords = (p1 - base + 31u) >> 5;
+	for (uint32_t i = threadIdx.x & 63u; i < nwords; i += 64u) {
+		const uint32_t v = atomicExch(&o.wave_words[i], 0u);
+		const uint32_t wb = base + 32u * i;
+		uint32_t *g = seg_words32 + (wb >> 5);
+		if (wb >= p0 && wb + 32u <= p1) {
+			*g = v;
+		} else if (v) {
+			atomicOr(g, v);
+		}
+	}
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int W, typename U, int OP, bool V>
 __device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint32_t r0, uint32_t r1,
                                            const adac_segment_desc &d, const RangePred &pred, bool linear,
-                                           const uint64_t *__restrict__ validity, uint64_t &acc) {
+                                           const uint64_t *__restrict__ validity, const SelOut &sel_out,
+                                           uint64_t &acc) {
 	constexpr int MAXV = (128 + W - 1) / W;
 	constexpr uint32_t mask = W >= 32 ? 0xffffffffu : ((1u << W) - 1u);
+	constexpr bool PRED = OP == 1 || OP == 3;
+	constexpr uint32_t STRIDE = OP == 3 ? 64u : (uint32_t)kWorkgroup;
 	const uint32_t c0 = (uint32_t)(((uint64_t)r0 * W) >> 7);       // r0 is a multiple of 128 rows
 	const uint32_t c1 = (uint32_t)(((uint64_t)r1 * W + 127) >> 7);
 	const uint32_t clast = (uint32_t)(((uint64_t)d.count * W + 127) >> 7) - 1; // last chunk holding data bits
 	const uint64_t add = linear ? widened_min<U>(d, pred.sbit) : 0ull;
-	FieldRange fr {0u, 0u, 0u, true};
-	if (OP == 1) {
+	FieldRange fr {0u, 0u, true};
+	if (PRED) {
 		fr = field_range<U>(pred, d, mask, linear);
 		if (!fr.any) return; // zonemap-style skip: no row of this segment can satisfy the predicate
 	}
+	// lane -> chunk map.  Aggregates: the workgroup strides over the run together.  Selection: each wave takes a
+	// contiguous quarter and whole waves stay in the loop (Lw is the wave's first chunk; lanes past `lend`
+	// carry no rows)
+	uint32_t L, Lw, lend;
+	if (OP == 3) {
+		const uint32_t per_wave = ((c1 - c0 + kWorkgroup - 1) / kWorkgroup) * 64u;
+		Lw = c0 + (threadIdx.x >> 6) * per_wave;
+		lend = Lw + per_wave < c1 ? Lw + per_wave : c1;
+		L = Lw + (threadIdx.x & 63u);
+	} else {
+		L = Lw = c0 + threadIdx.x;
+		lend = c1;
+	}
+	if (Lw >= lend) return;
+	// selection bookkeeping (wave-uniform)
+	const uint32_t sh0 = (uint32_t)(d.val_off & 31u);
+	uint32_t *seg_words32 = sel_out.bitmap32 + (d.val_off >> 5);
+	uint32_t blk_p0 = 0, blk_iter = 0;
+	bool blk_any = false;
 	// software pipeline: the next chunk's loads are issued (unconditionally, index clamped into the segment)
 	// before the current chunk is decoded, so a wave always has a load in flight
-	uint32_t L = c0 + threadIdx.x;
-	if (L >= c1) return;
-	uint4 q = seg16[L];
-	uint32_t e = reinterpret_cast<const uint32_t *>(seg16 + (L < clast ? L + 1 : clast))[0];
-	for (; L < c1; L += kWorkgroup) {
-		const uint32_t Lp = L + kWorkgroup < clast ? L + kWorkgroup : clast;
+	const uint32_t Lc = L < clast ? L : clast;
+	uint4 q = seg16[Lc];
+	uint32_t e = reinterpret_cast<const uint32_t *>(seg16 + (Lc < clast ? Lc + 1 : clast))[0];
+	for (; Lw < lend; L += STRIDE, Lw += STRIDE) {
+		const uint32_t Lp = L + STRIDE < clast ? L + STRIDE : clast;
 		const uint4 qn = seg16[Lp];
 		const uint32_t en = reinterpret_cast<const uint32_t *>(seg16 + (Lp < clast ? Lp + 1 : clast))[0];
 		const uint32_t i0 = (128u * L + (W - 1)) / W; // first row starting in this chunk
@@ -473,26 +561,60 @@ __device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint
 		}
 		const uint32_t starting = (128u - o0 + (W - 1)) / W; // rows starting in the chunk: MAXV-1 or MAXV
 		const uint32_t lim = r1 > i0 ? r1 - i0 : 0u;
-		ChunkAgg<W, U, OP> agg;
+		if (PRED) {
+			// bit j of `hits` = row i0 + j satisfies the predicate: built top-down so that each field costs
+			// extract, subtract, compare and one add-with-carry (hits = 2 * hits + hit)
+			uint32_t have = starting < lim ? starting : lim;
+			if (OP == 3 && L >= lend) have = 0u; // the next wave's chunk
+			uint32_t hits = 0;
+#pragma unroll
+			for (int j = MAXV - 1; j >= 0; j--) {
+				hits = hits + hits + (((field_of<W>(nrm, j) - fr.flo) <= fr.span) ? 1u : 0u);
+			}
+			hits &= have >= 32u ? 0xffffffffu : ((1u << have) - 1u);
+			const uint32_t at = i0 < r1 ? i0 : r1; // keeps a lane's element range inside this run
+			// NULL rows (DuckDB validity mask over the element index space) take no part
+			if (V) hits &= validity_window(validity, d.val_off + at);
+			acc += (uint32_t)__popc(hits);
+			if (OP == 3) {
+				if (blk_iter == 0) {
+					const uint32_t iw0 = (128u * Lw + (W - 1)) / W;
+					blk_p0 = sh0 + (iw0 < r1 ? iw0 : r1);
+				}
+				blk_any = blk_any || __builtin_amdgcn_ballot_w64(hits != 0u) != 0ull;
+				sel_or(sel_out, blk_p0 & ~31u, sh0 + at, hits, have);
+				blk_iter++;
+				const uint32_t Lw1 = Lw + 64u < lend ? Lw + 64u : lend;
+				if (blk_iter == kSelBlock || Lw1 == lend) {
+					if (blk_any) { // nothing selected since the last flush: the bitmap is already clear there
+						const uint32_t iw1 = (128u * Lw1 + (W - 1)) / W;
+						sel_flush(sel_out, seg_words32, blk_p0, sh0 + (iw1 < r1 ? iw1 : r1));
+					}
+					blk_iter = 0;
+					blk_any = false;
+				}
+			}
+			continue;
+		}
+		ChunkSum<W> agg;
 		uint32_t nv = 0;
 		if (V) {
-			// NULL rows (DuckDB validity mask over the element index space) take no part in the aggregate
 			const uint32_t vbits = validity_window(validity, d.val_off + i0);
 			const uint32_t have = starting < lim ? starting : lim;
 #pragma unroll
 			for (int j = 0; j < MAXV; j++) {
-				if ((uint32_t)j < have) agg.add_if(field_of<W>(nrm, j), fr, (vbits >> j) & 1u);
+				if ((uint32_t)j < have) agg.add_if(field_of<W>(nrm, j), (vbits >> j) & 1u);
 			}
 		} else if (starting <= lim) { // interior chunk: only the last slot may be absent
 			nv = starting;
 #pragma unroll
-			for (int j = 0; j < MAXV - 1; j++) agg.add(field_of<W>(nrm, j), fr);
-			if (128 % W == 0 || starting == (uint32_t)MAXV) agg.add(field_of<W>(nrm, MAXV - 1), fr);
+			for (int j = 0; j < MAXV - 1; j++) agg.add(field_of<W>(nrm, j));
+			if (128 % W == 0 || starting == (uint32_t)MAXV) agg.add(field_of<W>(nrm, MAXV - 1));
 		} else { // the run ends inside this chunk
 			nv = lim;
 #pragma unroll
 			for (int j = 0; j < MAXV; j++) {
-				if ((uint32_t)j < nv) agg.add(field_of<W>(nrm, j), fr);
+				if ((uint32_t)j < nv) agg.add(field_of<W>(nrm, j));
 			}
 		}
 		acc += agg.total(nv, add);
@@ -502,9 +624,10 @@ __device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint
 template <typename U, int OP, bool V>
 __device__ __forceinline__ void scan_run_dispatch(uint32_t w, const uint4 *__restrict__ seg16, uint32_t r0,
                                                   uint32_t r1, const adac_segment_desc &d, const RangePred &pred,
-                                                  bool linear, const uint64_t *__restrict__ validity, uint64_t &acc) {
+                                                  bool linear, const uint64_t *__restrict__ validity,
+                                                  const SelOut &sel_out, uint64_t &acc) {
 	switch (w) {
-#define ADAC_W(N) case N: scan_run_w<N, U, OP, V>(seg16, r0, r1, d, pred, linear, validity, acc); break;
+#define ADAC_W(N) case N: scan_run_w<N, U, OP, V>(seg16, r0, r1, d, pred, linear, validity, sel_out, acc); break;
 		ADAC_W(4) ADAC_W(5) ADAC_W(6) ADAC_W(7) ADAC_W(8) ADAC_W(9) ADAC_W(10) ADAC_W(11) ADAC_W(12) ADAC_W(13)
 		ADAC_W(14) ADAC_W(15) ADAC_W(16) ADAC_W(17) ADAC_W(18) ADAC_W(19) ADAC_W(20) ADAC_W(21) ADAC_W(22)
 		ADAC_W(23) ADAC_W(24) ADAC_W(25) ADAC_W(26) ADAC_W(27) ADAC_W(28) ADAC_W(29) ADAC_W(30) ADAC_W(31) ADAC_W(32)
@@ -513,15 +636,23 @@ __device__ __forceinline__ void scan_run_dispatch(uint32_t w, const uint4 *__res
 	}
 }
 
-template <typename U, int OP, bool V> // OP 0: SUM, 1: COUNT(lo <= v <= hi), 2: load-only probe; V: validity mask given
-__global__ __launch_bounds__(kWorkgroup) void k_scan_agg(const adac_segment_desc *__restrict__ descs,
+// OP 0: SUM, 1: COUNT(lo <= v <= hi), 2: load-only probe, 3: COUNT + selection bitmap; V: validity mask given
+template <typename U, int OP, bool V>
+__global__ __launch_bounds__(kWorkgroup, 6) void k_scan_agg(const adac_segment_desc *__restrict__ descs,
                                                          const TileRef *__restrict__ tiles, uint32_t ntiles,
                                                          uint32_t group, int templated,
                                                          const uint64_t *__restrict__ words, RangePred pred,
                                                          const uint64_t *__restrict__ validity,
-                                                         uint64_t *__restrict__ result) {
+                                                         uint64_t *__restrict__ result, uint32_t *__restrict__ bitmap32) {
 	constexpr uint32_t TILE = kTileBytes / sizeof(U);
 	__shared__ uint4 lds[kTileBytes / 16 + 2];
+	__shared__ uint32_t sel_words[OP == 3 ? (kWorkgroup / 64) * kSelWordsPerWave : 1];
+	SelOut sel_out {sel_words, bitmap32};
+	if (OP == 3) {
+		sel_out.wave_words = sel_words + (threadIdx.x >> 6) * kSelWordsPerWave;
+		for (uint32_t i = threadIdx.x & 63u; i < (uint32_t)kSelWordsPerWave; i += 64u) sel_out.wave_words[i] = 0u;
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	}
 	const uint32_t *lds32 = reinterpret_cast<const uint32_t *>(lds);
 	uint32_t t = blockIdx.x * group;
 	const uint32_t hi = t + group < ntiles ? t + group : ntiles;
@@ -544,8 +675,9 @@ __global__ __launch_bounds__(kWorkgroup) void k_scan_agg(const adac_segment_desc
 		const uint32_t w = d.width;
 		const SegKind kind = seg_kind<U>(d, pred.sbit);
 		// the register path works on fields: linear segments, and raw ones whose field IS the value it needs
-		// (SUM: unsigned T; COUNT: any T the 32-bit field holds whole)
-		const bool by_field = kind == SEG_LINEAR || (kind == SEG_RAW && (OP == 1 ? sizeof(U) <= 4 : pred.sbit == 0));
+		// (unsigned T; for the predicates also 32-bit signed T, whose order is a shift of the field's)
+		const bool by_field = kind == SEG_LINEAR ||
+		                      (kind == SEG_RAW && (pred.sbit == 0 || ((OP == 1 || OP == 3) && sizeof(U) == 4)));
 		if (templated && w >= 4 && w <= 32 && (uint64_t)d.count * w < (1ull << 31) && by_field) {
 			// width-templated register path: the whole run of this segment's tiles in this group, no LDS
 			// tiles of one segment are consecutive table entries, so the run length is arithmetic (walking the
@@ -555,7 +687,8 @@ __global__ __launch_bounds__(kWorkgroup) void k_scan_agg(const adac_segment_desc
 			const uint32_t run = tiles_left < hi - t ? tiles_left : hi - t;
 			const uint32_t n = left < run * TILE ? left : run * TILE;
 			const uint4 *seg16 = reinterpret_cast<const uint4 *>(words + d.word_off);
-			scan_run_dispatch<U, OP, V>(w, seg16, r.first, r.first + n, d, pred, kind == SEG_LINEAR, validity, acc);
+			scan_run_dispatch<U, OP, V>(w, seg16, r.first, r.first + n, d, pred, kind == SEG_LINEAR, validity, sel_out,
+			                            acc);
 			t += run;
 			continue;
 		}
@@ -572,6 +705,19 @@ __global__ __launch_bounds__(kWorkgroup) void k_scan_agg(const adac_segment_desc
 		auto sink = [&](int32_t base, const U *vals, bool full) {
 			constexpr int KK = 16 / (int)sizeof(U);
 			const uint32_t vbits = V ? validity_window(validity, elem0 + (uint32_t)(base < 0 ? 0 : base)) : 0xffffffffu;
+			if (OP == 3) { // decode_run walks with align 0: base >= 0, lanes ascending
+				uint32_t hits = 0;
+#pragma unroll
+				for (int j = 0; j < KK; j++) {
+					hits |= (((((uint64_t)vals[j] ^ pred.sbit) - pred.blo) <= pred.bspan) ? 1u : 0u) << j;
+				}
+				const uint32_t left = n - (uint32_t)base;
+				const uint32_t have = full || left >= (uint32_t)KK ? (uint32_t)KK : left;
+				hits &= vbits & ((1u << have) - 1u);
+				acc += (uint32_t)__popc(hits);
+				wave_emit_bits(sel_out, elem0 + (uint32_t)base, hits, have);
+				return;
+			}
 #pragma unroll
 			for (int j = 0; j < KK; j++) {
 				if ((full || (uint32_t)(base + j) < n) && ((vbits >> j) & 1u)) {
@@ -1076,15 +1222,18 @@ hipError_t launch_scan_sum(hipStream_t s, uint32_t type_size, const adac_segment
 		const dim3 grid((unsigned)((ntiles + per - 1) / per));
 		if (g_tuning.scan_probe) { // diagnostic: the scan's loop and loads without the field walk (result meaningless)
 			hipLaunchKernelGGL((k_scan_agg<U, 2, false>), grid, dim3(kWorkgroup), 0, s, d_descs, d_tiles, (uint32_t)ntiles, per,
-			                   1, d_words, RangePred {}, static_cast<const uint64_t *>(nullptr), d_sums);
+			                   1, d_words, RangePred {}, static_cast<const uint64_t *>(nullptr), d_sums,
+			                   static_cast<uint32_t *>(nullptr));
 			return hipGetLastError();
 		}
 		if (d_validity) {
 			hipLaunchKernelGGL((k_scan_agg<U, 0, true>), grid, dim3(kWorkgroup), 0, s, d_descs, d_tiles, (uint32_t)ntiles,
-			                   per, g_tuning.templated_scan, d_words, widen, d_validity, d_sums);
+			                   per, g_tuning.templated_scan, d_words, widen, d_validity, d_sums,
+			                   static_cast<uint32_t *>(nullptr));
 		} else {
 			hipLaunchKernelGGL((k_scan_agg<U, 0, false>), grid, dim3(kWorkgroup), 0, s, d_descs, d_tiles,
-			                   (uint32_t)ntiles, per, g_tuning.templated_scan, d_words, widen, d_validity, d_sums);
+			                   (uint32_t)ntiles, per, g_tuning.templated_scan, d_words, widen, d_validity, d_sums,
+			                   static_cast<uint32_t *>(nullptr));
 		}
 		return hipGetLastError();
 	});
@@ -1093,20 +1242,25 @@ hipError_t launch_scan_sum(hipStream_t s, uint32_t type_size, const adac_segment
 hipError_t launch_scan_count_range(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs,
                                    const TileRef *d_tiles, uint64_t ntiles, const uint64_t *d_words,
                                    const uint64_t *d_validity, uint64_t blo, uint64_t bspan, uint64_t sbit,
-                                   uint64_t *d_counts) {
+                                   uint64_t *d_counts, uint64_t *d_bitmap) {
 	if (ntiles == 0) return hipSuccess;
 	return dispatch_size(type_size, [&](auto tag) {
 		using U = decltype(tag);
 		const uint32_t per = (uint32_t)g_tuning.scan_tiles_per_wg;
 		const dim3 grid((unsigned)((ntiles + per - 1) / per));
 		const RangePred pred {blo, bspan, sbit};
-		if (d_validity) {
-			hipLaunchKernelGGL((k_scan_agg<U, 1, true>), grid, dim3(kWorkgroup), 0, s, d_descs, d_tiles, (uint32_t)ntiles,
-			                   per, g_tuning.templated_scan, d_words, pred, d_validity, d_counts);
+		uint32_t *bm = reinterpret_cast<uint32_t *>(d_bitmap);
+		const uint32_t nt = (uint32_t)ntiles;
+		const int tpl = g_tuning.templated_scan;
+#define ADAC_SCAN(OPN, VAL)                                                                                            \
+	hipLaunchKernelGGL((k_scan_agg<U, OPN, VAL>), grid, dim3(kWorkgroup), 0, s, d_descs, d_tiles, nt, per, tpl,       \
+	                   d_words, pred, d_validity, d_counts, bm)
+		if (d_bitmap) {
+			if (d_validity) ADAC_SCAN(3, true); else ADAC_SCAN(3, false);
 		} else {
-			hipLaunchKernelGGL((k_scan_agg<U, 1, false>), grid, dim3(kWorkgroup), 0, s, d_descs, d_tiles,
-			                   (uint32_t)ntiles, per, g_tuning.templated_scan, d_words, pred, d_validity, d_counts);
+			if (d_validity) ADAC_SCAN(1, true); else ADAC_SCAN(1, false);
 		}
+#undef ADAC_SCAN
 		return hipGetLastError();
 	});
 }

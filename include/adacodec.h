@@ -251,6 +251,17 @@ adac_status adac_scan_sum_valid(adac_layout *l, const uint64_t *d_words, const u
 adac_status adac_scan_count_between_valid(adac_layout *l, const uint64_t *d_words, const uint64_t *d_validity,
                                           uint64_t lo, uint64_t hi, uint64_t *d_counts);
 
+/* Filter push-down with a selection result — ColumnSegment::FilterSelection (column_segment.cpp:575-844) on the
+ * packed bytes: bit e of d_bitmap (element index e = val_off + row, the same index space as the validity mask) is
+ * set iff the row is valid (d_validity, NULL = every row) and lo <= value <= hi in T's own order; d_counts[seg] =
+ * rows selected.  d_bitmap has ceil(value_span / 64) words, is cleared by the call and must not alias
+ * d_validity.  Because the result has the validity mask's layout it can be handed to the next column's scan
+ * (adac_scan_select_between again for a conjunction, adac_scan_sum_valid / adac_scan_count_between_valid for the
+ * aggregate) when the columns share their value offsets: a multi-column filter + aggregate (TPC-H Q6's shape)
+ * that never materialises a value. */
+adac_status adac_scan_select_between(adac_layout *l, const uint64_t *d_words, const uint64_t *d_validity, uint64_t lo,
+                                     uint64_t hi, uint64_t *d_bitmap, uint64_t *d_counts);
+
 /* ---------------------------------------------------------------------------------------------
  * DuckDB BITPACKING segments — the persistent counterpart of the succinct codec, decode side.
  * A segment is the block image DuckDB's checkpoint writes (src/storage/compression/bitpacking.cpp:357-538):

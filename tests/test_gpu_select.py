@@ -1,0 +1,154 @@
+"""adac_scan_select_between: the filter scan with a selection-bitmap result (ColumnSegment::FilterSelection,
+column_segment.cpp:575-844, evaluated on the packed bytes).  Expected bitmaps are built with numpy from the
+original values; the packed words themselves are checked against the oracle by run_encode_decode."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import make_values, run_encode_decode, wide_sum
+
+pytestmark = pytest.mark.gpu
+
+
+def bit_pattern(v, dtype):
+    dtype = np.dtype(dtype)
+    return int(np.array([v]).astype(dtype).view(np.dtype("u%d" % dtype.itemsize))[0])
+
+
+def pack_mask(bits, span):
+    """bool per element -> u64 words of a DuckDB validity-style mask (+ one spare word)."""
+    full = np.zeros(span, dtype=bool)
+    full[:len(bits)] = bits
+    b = np.packbits(full, bitorder="little")
+    return np.concatenate([b, np.zeros((-len(b)) % 8 + 8, np.uint8)]).view(np.uint64)
+
+
+def expected_bitmap(segs, offs, span, lo, hi, valid=None):
+    sel = np.zeros(span, dtype=bool)
+    for v, o in zip(segs, offs):
+        hit = (v >= lo) & (v <= hi)
+        if valid is not None:
+            hit &= valid[o:o + len(v)]
+        sel[o:o + len(v)] = hit
+    return sel
+
+
+def check_select(adac, ctx, lay, d_words, dtype, segs, offs, span, probes, valid=None):
+    nw = (span + 63) // 64
+    d_bm = ctx.alloc(nw * 8 + 8)
+    d_cnt = ctx.alloc(len(segs) * 8)
+    d_valid = None if valid is None else ctx.upload(pack_mask(valid, span))
+    try:
+        for templated in (1, 0):
+            adac.set_tuning("templated_scan", templated)
+            for group in (16, 3):
+                adac.set_tuning("scan_tiles_per_wg", group)
+                for lo, hi in probes:
+                    d_bm.upload(np.full(nw + 1, 0xDEADBEEFDEADBEEF, dtype=np.uint64))  # the call clears it
+                    lay.scan_select_between(d_words, bit_pattern(lo, dtype), bit_pattern(hi, dtype), d_bm, d_cnt, d_valid)
+                    got = d_bm.download(np.uint64, nw + 1)
+                    assert int(got[nw]) == 0xDEADBEEFDEADBEEF          # nothing past ceil(span / 64) words
+                    exp = expected_bitmap(segs, offs, span, lo, hi, valid)
+                    bits = np.unpackbits(got[:nw].view(np.uint8), bitorder="little")[:span].astype(bool)
+                    bad = np.flatnonzero(bits != exp)
+                    assert bad.size == 0, (np.dtype(dtype).name, templated, group, lo, hi, bad[:8].tolist())
+                    tail = np.unpackbits(got[:nw].view(np.uint8), bitorder="little")[span:]
+                    assert not tail.any()
+                    cnt = d_cnt.download(np.uint64, len(segs)).tolist()
+                    assert cnt == [int(exp[o:o + len(v)].sum()) for v, o in zip(segs, offs)]
+    finally:
+        adac.set_tuning("templated_scan", 1)
+        adac.set_tuning("scan_tiles_per_wg", 16)
+
+
+@pytest.mark.parametrize("dtype", [np.uint64, np.int64, np.uint32, np.int32, np.uint16, np.int16, np.uint8, np.int8])
+def test_select_bitmap_every_path(adac, oracle, gpu_ctx, dtype):
+    dtype = np.dtype(dtype)
+    tb = 8 * dtype.itemsize
+    info = np.iinfo(dtype)
+    rng = np.random.default_rng(900 + tb + (dtype.kind == "i"))
+    tile = adac.tile_values(dtype)
+    widths = sorted({1, 3, 4, 5, 8, 13, 16, 21, 31, 32, 33, 47, tb - 1, tb} & set(range(1, tb + 1)))
+    counts, segs = [], []
+    for w in widths:
+        n = int(rng.integers(50, 3 * tile)) if w % 2 else 2 * tile + 1
+        counts.append(n)
+        segs.append(make_values(rng, dtype, n, w))
+    counts += [1, 0, 7]
+    segs += [make_values(rng, dtype, 1, 3), make_values(rng, dtype, 0, 3), make_values(rng, dtype, 7, 2)]
+    counts = np.array(counts, dtype=np.uint32)
+    # segments at ragged element offsets: bitmap words are shared between neighbouring segments and have gaps
+    offs, run = [], 0
+    for i, c in enumerate(counts):
+        run += (3, 0, 17, 1)[i % 4]
+        offs.append(run)
+        run += int(c)
+    span = run
+    lay, d_words, _, descs, _ = run_encode_decode(adac, oracle, gpu_ctx, dtype, counts, segs,
+                                                  val_offs=np.array(offs, dtype=np.uint64))
+    assert lay.value_span == span
+    a, b = sorted((int(segs[3][1]), int(segs[3][5])))
+    mid = segs[len(widths) // 2]
+    probes = [(a, b), (int(info.min), int(info.max)), (int(mid.min()), int(mid.min())), (int(mid[0]), int(info.max)),
+              (int(info.min), int(mid[1])), (5, 3)]
+    check_select(adac, gpu_ctx, lay, d_words, dtype, segs, offs, span, probes)
+    valid = rng.random(span) > 0.4
+    check_select(adac, gpu_ctx, lay, d_words, dtype, segs, offs, span, probes[:3], valid)
+
+
+def test_select_on_recompacted_and_sign_crossing_segments(adac, oracle, gpu_ctx):
+    rng = np.random.default_rng(4)
+    dtype = np.dtype(np.int32)
+    info = np.iinfo(dtype)
+    n = 30_000
+    cross = ((np.uint64(info.max - 100) + rng.integers(0, 200, size=n).astype(np.uint64)) & np.uint64(0xFFFFFFFF)) \
+        .astype(np.uint32).view(np.int32)
+    neg = rng.integers(-5000, -4000, size=n).astype(dtype)
+    pos = rng.integers(100, 90_000, size=n).astype(dtype)
+    segs = [cross, neg, pos]
+    counts = np.array([n, n, n], dtype=np.uint32)
+    lay, d_words, _, descs, _ = run_encode_decode(adac, oracle, gpu_ctx, dtype, counts, segs, adac.RULE_RECOMPACT)
+    assert all(descs["flags"] & adac.SEG_PACKED)
+    offs = [0, n, 2 * n]
+    probes = [(int(info.max) - 20, int(info.max)), (int(info.min), int(info.min) + 20), (-4500, 500), (-1, 1)]
+    check_select(adac, gpu_ctx, lay, d_words, dtype, segs, offs, 3 * n, probes)
+
+
+def test_conjunction_and_aggregate_without_materialising(adac, oracle, gpu_ctx):
+    """Q6's shape: WHERE a BETWEEN .. AND b BETWEEN .. AND c < .. -> SUM(d), all on packed columns that share
+    their segment layout; the selection of one scan is the validity mask of the next."""
+    rng = np.random.default_rng(6)
+    n = 1_000_003
+    counts = adac.appender_segment_counts(n, 4)
+    offs = [int(x) for x in np.concatenate([[0], np.cumsum(counts)[:-1]])]
+    cols = {"shipdate": rng.integers(8000, 10600, size=n).astype(np.int32),
+            "discount": rng.integers(0, 11, size=n).astype(np.int32),
+            "quantity": rng.integers(1, 51, size=n).astype(np.int32),
+            "price": rng.integers(90_000, 10_500_000, size=n).astype(np.int32)}
+    enc = {}
+    for name, v in cols.items():
+        lay = adac.Layout(gpu_ctx, np.int32, counts)
+        d_vals = gpu_ctx.upload(v)
+        d_words = gpu_ctx.alloc(lay.max_arena_words * 8 + 16).zero()
+        lay.encode(d_vals, d_words)
+        enc[name] = (lay, d_words)
+    nw = (n + 63) // 64
+    bm = [gpu_ctx.alloc(nw * 8) for _ in range(3)]
+    d_cnt = gpu_ctx.alloc(len(counts) * 8)
+    d_sum = gpu_ctx.alloc(len(counts) * 8)
+    lay, w = enc["shipdate"]
+    lay.scan_select_between(w, 8766, 9130, bm[0], d_cnt)
+    m = (cols["shipdate"] >= 8766) & (cols["shipdate"] <= 9130)
+    assert int(d_cnt.download(np.uint64, len(counts)).sum()) == int(m.sum())
+    lay, w = enc["discount"]
+    lay.scan_select_between(w, 5, 7, bm[1], d_cnt, bm[0])
+    m &= (cols["discount"] >= 5) & (cols["discount"] <= 7)
+    assert int(d_cnt.download(np.uint64, len(counts)).sum()) == int(m.sum())
+    lay, w = enc["quantity"]
+    lay.scan_select_between(w, bit_pattern(np.iinfo(np.int32).min, np.int32), 23, bm[2], d_cnt, bm[1])
+    m &= cols["quantity"] < 24
+    assert int(d_cnt.download(np.uint64, len(counts)).sum()) == int(m.sum())
+    lay, w = enc["price"]
+    lay.scan_sum(w, d_sum, bm[2])
+    got = d_sum.download(np.uint64, len(counts)).tolist()
+    assert got == [wide_sum(cols["price"][o:o + int(c)][m[o:o + int(c)]]) for o, c in zip(offs, counts)]
+    assert m.sum() > 1000

@@ -58,7 +58,9 @@ def main():
         rd = int(((descs["count"].astype(np.uint64) * descs["width"] + 63) // 64 * 8).sum())
         wr = rows * dtype.itemsize
         ref_sum = int(vals.astype(np.uint64).sum(dtype=np.uint64))
-        times = {name: {"unpack": [], "sum": []} for name, _ in variants}
+        times = {name: {"unpack": [], "sum": [], "count": [], "select": []} for name, _ in variants}
+        d_bm = ctx.alloc((rows + 63) // 64 * 8 + 8)
+        lo_key, hi_key = (1 << w) // 4, (1 << w) // 2   # ~25 % selectivity on the uniform test column
         for _ in range(rounds):
             for name, knobs in variants:
                 for k, v in knobs.items():
@@ -74,6 +76,14 @@ def main():
                 for _i in range(5):
                     lay.scan_sum(d_words, d_sums)
                 times[name]["sum"].append(ctx.timer_stop() / 5)
+                ctx.timer_start()
+                for _i in range(5):
+                    lay.scan_count_between(d_words, lo_key, hi_key, d_sums)
+                times[name]["count"].append(ctx.timer_stop() / 5)
+                ctx.timer_start()
+                for _i in range(5):
+                    lay.scan_select_between(d_words, lo_key, hi_key, d_bm, d_sums)
+                times[name]["select"].append(ctx.timer_stop() / 5)
         # every variant must still be right
         for name, knobs in variants:
             for k, v in knobs.items():
@@ -85,6 +95,11 @@ def main():
             assert np.array_equal(d_out.download(dtype, rows), vals), name
             if not knobs.get("scan_probe"):
                 assert int(d_sums.download(np.uint64, len(counts)).sum(dtype=np.uint64)) == ref_sum, name
+                ref_cnt = int(((vals >= lo_key) & (vals <= hi_key)).sum())
+                lay.scan_count_between(d_words, lo_key, hi_key, d_sums)
+                assert int(d_sums.download(np.uint64, len(counts)).sum()) == ref_cnt, name
+                lay.scan_select_between(d_words, lo_key, hi_key, d_bm, d_sums)
+                assert int(d_sums.download(np.uint64, len(counts)).sum()) == ref_cnt, name
         case = {"dtype": "u%d" % (8 * dtype.itemsize), "width": w, "variants": {}}
         for name, _ in variants:
             mu = float(np.median(times[name]["unpack"]))
@@ -94,9 +109,11 @@ def main():
                 "unpack_total_GBps": (rd + wr) / mu / 1e6, "unpack_Gvalues_s": rows / mu / 1e6,
                 "sum_ms_median": ms, "sum_ms_min": float(min(times[name]["sum"])),
                 "sum_read_GBps": rd / ms / 1e6, "sum_Gvalues_s": rows / ms / 1e6,
+                "count_read_GBps": rd / float(np.median(times[name]["count"])) / 1e6,
+                "select_read_GBps": rd / float(np.median(times[name]["select"])) / 1e6,
             }
         out["cases"].append(case)
-        del lay, d_vals, d_words, d_out, d_sums
+        del lay, d_vals, d_words, d_out, d_sums, d_bm
     adac.set_tuning("scan_probe", 0)
     print(json.dumps(out))
 
