@@ -163,13 +163,35 @@ def run_sweep(adac, torch, ctx, base_rows, steps):
             torch.cuda.synchronize()
             col.layout.scan_sum(col.d_words, d_sums)
             ms_sum = time_launches(ctx, lambda: col.layout.scan_sum(col.d_words, d_sums), steps)
+            # re-compaction packed -> packed: the column re-encoded with byte-padded widths, then back to exact
+            # widths (n (old_w + new_w) / 8 bytes)
+            pad = adac.Layout(ctx, dtype, counts)
+            d_pad = torch.zeros(pad.max_arena_words + 16, dtype=torch.int64, device="cuda:%d" % ctx.device)
+            exact = adac.Layout(ctx, dtype, counts)
+            d_exact = torch.zeros(exact.max_arena_words + 16, dtype=torch.int64, device="cuda:%d" % ctx.device)
+            torch.cuda.synchronize()
+            col.layout.reencode(col.d_words, pad, d_pad, None, adac.RULE_APPEND, True)
+            pd = pad.get_descs()
+            rd_pad = int(((pd["count"].astype(np.uint64) * pd["width"] + 63) // 64 * 8).sum())
+            rep = lambda: pad.reencode(d_pad, exact, d_exact, None, adac.RULE_APPEND, False)
+            rep()
+            ctx.sync()
+            ed = exact.get_descs()
+            assert np.array_equal(ed["width"], descs["width"]) and torch.equal(d_exact[:16384], col.d_words[:16384])
+            ms_rep = time_launches(ctx, rep, steps)
+            rp = lambda: pad.repack(d_pad, exact, d_exact)
+            ms_rp = time_launches(ctx, rp, steps)
+            repack = {"old_widths": sorted(set(pd["width"].tolist())), "reencode_ms": ms_rep, "repack_kernel_ms": ms_rp,
+                      "repack_GBps": (rd_pad + rd) / (ms_rp * 1e-3) / 1e9,
+                      "reencode_values_per_s": rows / (ms_rep * 1e-3)}
+            del pad, d_pad, exact, d_exact
             d_bm = torch.zeros((rows + 63) // 64 + 1, dtype=torch.int64, device="cuda:%d" % ctx.device)
             torch.cuda.synchronize()
             sel = lambda: col.layout.scan_select_between(col.d_words, 0, 2 ** (w - 1), d_bm, d_sums)
             sel()
             ms_sel = time_launches(ctx, sel, steps)
             out.append({
-                "select_read_GBps": rd / (ms_sel * 1e-3) / 1e9,
+                "select_read_GBps": rd / (ms_sel * 1e-3) / 1e9, "recompaction": repack,
                 "dtype": "u%d" % (8 * dtype.itemsize), "width": w, "rows": rows,
                 "widths_seen": sorted(set(descs["width"].tolist())),
                 "decode_values_per_s": rows / (ms * 1e-3),

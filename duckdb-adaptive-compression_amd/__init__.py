@@ -120,6 +120,9 @@ SIGNATURES = {
     "adac_plan": (_int, [_vp, _int, _int]),
     "adac_pack": (_int, [_vp, _vp, _vp, _vp]),
     "adac_encode": (_int, [_vp, _vp, _vp, _int, _int, _vp]),
+    "adac_analyze_packed": (_int, [_vp, _vp, _vp, _int, _vp]),
+    "adac_repack": (_int, [_vp, _vp, _vp, _vp, _vp]),
+    "adac_reencode": (_int, [_vp, _vp, _vp, _int, _int, _vp, _vp]),
     "adac_unpack": (_int, [_vp, _vp, _vp]),
     "adac_unpack_range": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _u64]),
     "adac_fetch_rows": (_int, [_vp, _vp, _vp, _vp, _u64, _vp]),
@@ -376,6 +379,18 @@ class Layout:
     def encode(self, d_vals, d_words, d_validity=None, rule=RULE_APPEND, pad_to_byte=False):
         _check(lib().adac_encode(self._h, _dptr(d_vals), _dptr(d_validity), rule, int(pad_to_byte), _dptr(d_words)),
                "adac_encode")
+
+    def analyze_packed(self, d_words, dst, d_validity=None, rule=RULE_APPEND):
+        """min/max of this layout's decoded values, left in `dst` (a layout over the same segments) for dst.plan()."""
+        _check(lib().adac_analyze_packed(self._h, _dptr(d_words), _dptr(d_validity), rule, dst._h), "adac_analyze_packed")
+
+    def repack(self, d_words, dst, d_dst_words, d_validity=None):
+        _check(lib().adac_repack(self._h, _dptr(d_words), _dptr(d_validity), dst._h, _dptr(d_dst_words)), "adac_repack")
+
+    def reencode(self, d_words, dst, d_dst_words, d_validity=None, rule=RULE_APPEND, pad_to_byte=False):
+        """packed -> packed: dst gets the widths adac_encode would choose for the decoded values."""
+        _check(lib().adac_reencode(self._h, _dptr(d_words), _dptr(d_validity), rule, int(pad_to_byte), dst._h,
+                                   _dptr(d_dst_words)), "adac_reencode")
 
     def unpack(self, d_words, d_out):
         _check(lib().adac_unpack(self._h, _dptr(d_words), _dptr(d_out)), "adac_unpack")

@@ -488,6 +488,46 @@ extern "C" adac_status adac_encode(adac_layout *l, const void *d_vals, const uin
 	return adac_pack(l, d_vals, d_validity, d_words);
 }
 
+// packed -> packed re-compaction: both layouts describe the same segments (type, counts, value offsets)
+static bool same_shape(const adac_layout *a, const adac_layout *b) {
+	return a && b && a != b && a->ctx == b->ctx && a->type == b->type && a->counts == b->counts &&
+	       a->val_offs == b->val_offs;
+}
+
+extern "C" adac_status adac_analyze_packed(adac_layout *src, const uint64_t *d_src_words, const uint64_t *d_validity,
+                                           int rule, adac_layout *dst) {
+	if (!same_shape(src, dst) || (rule != ADAC_RULE_APPEND && rule != ADAC_RULE_RECOMPACT))
+		return ADAC_ERR_INVALID_ARGUMENT;
+	if ((!d_src_words && src->total_values) || !aligned16(d_src_words)) return ADAC_ERR_INVALID_ARGUMENT;
+	ADAC_HIP(hipSetDevice(src->ctx->device));
+	ADAC_HIP(adac::launch_minmax_init(src->ctx->stream, dst->d_minmax, dst->nseg));
+	ADAC_HIP(adac::launch_analyze_packed(src->ctx->stream, src->type_size, src->is_signed, src->null_bits, rule,
+	                                     src->d_descs, src->d_tiles, src->ntiles, d_src_words, d_validity,
+	                                     dst->d_minmax));
+	return ADAC_OK;
+}
+
+extern "C" adac_status adac_repack(adac_layout *src, const uint64_t *d_src_words, const uint64_t *d_validity,
+                                   adac_layout *dst, uint64_t *d_dst_words) {
+	if (!same_shape(src, dst)) return ADAC_ERR_INVALID_ARGUMENT;
+	if ((!d_src_words || !d_dst_words) && src->total_values) return ADAC_ERR_INVALID_ARGUMENT;
+	if (!aligned16(d_src_words) || !aligned16(d_dst_words) || d_src_words == d_dst_words)
+		return ADAC_ERR_INVALID_ARGUMENT;
+	ADAC_HIP(hipSetDevice(src->ctx->device));
+	ADAC_HIP(adac::launch_repack(src->ctx->stream, src->type_size, src->null_bits, src->d_descs, dst->d_descs,
+	                             src->d_tiles, src->ntiles, d_src_words, d_validity, d_dst_words));
+	return ADAC_OK;
+}
+
+extern "C" adac_status adac_reencode(adac_layout *src, const uint64_t *d_src_words, const uint64_t *d_validity,
+                                     int rule, int pad_to_byte, adac_layout *dst, uint64_t *d_dst_words) {
+	adac_status st = adac_analyze_packed(src, d_src_words, d_validity, rule, dst);
+	if (st != ADAC_OK) return st;
+	st = adac_plan(dst, rule, pad_to_byte);
+	if (st != ADAC_OK) return st;
+	return adac_repack(src, d_src_words, d_validity, dst, d_dst_words);
+}
+
 extern "C" adac_status adac_unpack(adac_layout *l, const uint64_t *d_words, void *d_out) {
 	if (!l || ((!d_words || !d_out) && l->total_values)) return ADAC_ERR_INVALID_ARGUMENT;
 	if (!aligned16(d_words) || !aligned16(d_out)) return ADAC_ERR_INVALID_ARGUMENT;

@@ -59,6 +59,12 @@ hipError_t launch_unpack_range(hipStream_t s, uint32_t type_size, const adac_seg
                                const uint64_t *d_words, void *d_out);
 hipError_t launch_fetch(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs, const uint64_t *d_words,
                         const uint32_t *d_segs, const uint32_t *d_rows, uint64_t n, void *d_out);
+hipError_t launch_analyze_packed(hipStream_t s, uint32_t type_size, bool sign_extend, uint64_t null_bits, int rule,
+                                 const adac_segment_desc *d_src_descs, const TileRef *d_tiles, uint64_t ntiles,
+                                 const uint64_t *d_src_words, const uint64_t *d_validity, uint64_t *d_minmax);
+hipError_t launch_repack(hipStream_t s, uint32_t type_size, uint64_t null_bits, const adac_segment_desc *d_src_descs,
+                         const adac_segment_desc *d_dst_descs, const TileRef *d_tiles, uint64_t ntiles,
+                         const uint64_t *d_src_words, const uint64_t *d_validity, uint64_t *d_dst_words);
 hipError_t launch_scan_sum(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs, const TileRef *d_tiles,
                            uint64_t ntiles, const uint64_t *d_words, const uint64_t *d_validity, uint64_t sbit, uint64_t *d_sums);
 hipError_t launch_scan_count_range(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs,

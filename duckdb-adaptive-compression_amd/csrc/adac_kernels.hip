@@ -1089,6 +1089,125 @@ __global__ __launch_bounds__(kWorkgroup) void k_pack(const adac_segment_desc *__
 }
 
 // ---------------------------------------------------------------------------------------------
+// Re-compaction packed -> packed (SURVEY.md §8b `adac_repack`, §8d "old_w -> new_w: n (old_w + new_w) / 8 bytes").
+// The reference only ever compacts from full-width slots (BitCompressFromSuccinct, column_segment.cpp:348-383);
+// these two kernels are the same two passes with a PACKED source: the tile's values come from decoding the
+// source segment's staged bits instead of from a raw array, everything downstream (min/max rules, width, the
+// word-owner pack) is shared with k_analyze / k_pack.  Source and destination layouts have the same counts.
+// ---------------------------------------------------------------------------------------------
+template <typename U>
+__global__ __launch_bounds__(kWorkgroup) void k_analyze_packed(const adac_segment_desc *__restrict__ src_descs,
+                                                               const TileRef *__restrict__ tiles,
+                                                               const uint64_t *__restrict__ src_words,
+                                                               const uint64_t *__restrict__ validity, int sign_extend,
+                                                               uint64_t null_bits, int rule,
+                                                               uint64_t *__restrict__ minmax) {
+	constexpr int TILE = kTileBytes / (int)sizeof(U);
+	using S = typename std::make_signed<U>::type;
+	__shared__ uint4 lds[kTileBytes / 16 + 2];
+	__shared__ uint64_t pmin[kWorkgroup / 64], pmax[kWorkgroup / 64];
+	const TileCtx t = resolve_tile<TILE>(src_descs, tiles);
+	const uint32_t bit0 = stage_packed(src_words + t.d.word_off, t.first, t.n, t.d.width, lds);
+	__syncthreads();
+	uint64_t mn = ~0ull, mx = 0;
+	auto sink = [&](int32_t base, const U *v, bool full) { // align 0: base >= 0
+		constexpr int K = 16 / (int)sizeof(U);
+		const uint32_t vbits = validity ? validity_window(validity, t.elem0 + (uint32_t)base) : 0xffffffffu;
+#pragma unroll
+		for (int j = 0; j < K; j++) {
+			if (!full && (uint32_t)(base + j) >= t.n) continue;
+			const bool valid = (vbits >> j) & 1u;
+			uint64_t x;
+			if (rule == ADAC_RULE_APPEND) { // succinct.cpp:286-287: NULL rows do not take part
+				if (!valid) continue;
+				x = sign_extend ? (uint64_t)(int64_t)(S)v[j] : (uint64_t)v[j];
+			} else { // column_segment.cpp:392-399: every slot, zero-extended; NULL slots hold NullValue<T>
+				x = valid ? (uint64_t)v[j] : null_bits;
+			}
+			mn = x < mn ? x : mn;
+			mx = x > mx ? x : mx;
+		}
+	};
+	decode_tile<U>(reinterpret_cast<const uint32_t *>(lds), bit0, t.d.width, effective_add(t.d), t.n, 0u, sink);
+	mn = wave_min(mn);
+	mx = wave_max(mx);
+	if ((threadIdx.x & 63) == 0) {
+		pmin[threadIdx.x >> 6] = mn;
+		pmax[threadIdx.x >> 6] = mx;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+#pragma unroll
+		for (int i = 1; i < kWorkgroup / 64; i++) {
+			mn = pmin[i] < mn ? pmin[i] : mn;
+			mx = pmax[i] > mx ? pmax[i] : mx;
+		}
+		atomicMin(reinterpret_cast<unsigned long long *>(minmax + 2 * (uint64_t)t.seg), (unsigned long long)mn);
+		atomicMax(reinterpret_cast<unsigned long long *>(minmax + 2 * (uint64_t)t.seg + 1), (unsigned long long)mx);
+	}
+}
+
+template <typename U>
+__global__ __launch_bounds__(kWorkgroup) void k_repack(const adac_segment_desc *__restrict__ src_descs,
+                                                       const adac_segment_desc *__restrict__ dst_descs,
+                                                       const TileRef *__restrict__ tiles,
+                                                       const uint64_t *__restrict__ src_words,
+                                                       const uint64_t *__restrict__ validity, uint64_t null_bits,
+                                                       uint64_t *__restrict__ dst_words) {
+	constexpr int TILE = kTileBytes / (int)sizeof(U);
+	__shared__ uint4 lds[kTileBytes / 16 + 2];
+	__shared__ __attribute__((aligned(16))) U delta[TILE];
+	const TileCtx t = resolve_tile<TILE>(src_descs, tiles);
+	const adac_segment_desc dd = dst_descs[t.seg];
+	const uint32_t w = dd.width;
+	const bool packed = (dd.flags & ADAC_SEG_PACKED) != 0;
+	const U sub = (U)((packed && dd.min != ADAC_NO_MIN) ? dd.min : 0ull); // column_segment.cpp:371-373
+	const U wmask = (U)mask64(w);
+	const uint32_t bit0 = stage_packed(src_words + t.d.word_off, t.first, t.n, t.d.width, lds);
+	__syncthreads();
+	auto sink = [&](int32_t base, const U *v, bool full) {
+		constexpr int K = 16 / (int)sizeof(U);
+		const uint32_t vbits = validity ? validity_window(validity, t.elem0 + (uint32_t)base) : 0xffffffffu;
+		if (full) {
+			U o[K];
+#pragma unroll
+			for (int j = 0; j < K; j++) {
+				const U x = ((vbits >> j) & 1u) ? v[j] : (U)null_bits;
+				o[j] = (U)(x - sub) & wmask;
+			}
+			uint4 q;
+			__builtin_memcpy(&q, o, 16);
+			*reinterpret_cast<uint4 *>(delta + base) = q; // base is a multiple of K: ds_write_b128
+		} else {
+#pragma unroll
+			for (int j = 0; j < K; j++) {
+				if ((uint32_t)(base + j) >= t.n) continue;
+				const U x = ((vbits >> j) & 1u) ? v[j] : (U)null_bits;
+				delta[base + j] = (U)(x - sub) & wmask;
+			}
+		}
+	};
+	decode_tile<U>(reinterpret_cast<const uint32_t *>(lds), bit0, t.d.width, effective_add(t.d), t.n, 0u, sink);
+	__syncthreads();
+	const uint64_t word0 = ((uint64_t)t.first * w) >> 6;
+	const uint32_t nwords = (t.n * w + 63u) >> 6;
+	uint64_t *__restrict__ dst = dst_words + dd.word_off + word0;
+	for (uint32_t q = threadIdx.x; q < nwords; q += kWorkgroup) { // word-owner gather, as in k_pack
+		const uint32_t bitlo = q << 6;
+		uint32_t i = bitlo / w;
+		uint32_t last = (bitlo + 63u) / w;
+		last = last < t.n ? last : t.n - 1;
+		uint64_t acc = 0;
+		for (; i <= last; i++) {
+			const uint64_t v = (uint64_t)delta[i];
+			const int32_t pos = (int32_t)(i * w) - (int32_t)bitlo;
+			acc |= pos >= 0 ? (v << pos) : (v >> (-pos));
+		}
+		dst[q] = acc;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_fetch — point look-ups straight from HBM (two 8-byte loads per row).
 // ---------------------------------------------------------------------------------------------
 template <typename U>
@@ -1166,6 +1285,30 @@ hipError_t launch_pack(hipStream_t s, uint32_t type_size, uint64_t null_bits, co
 		using U = decltype(tag);
 		hipLaunchKernelGGL(k_pack<U>, dim3((unsigned)ntiles), dim3(kWorkgroup), 0, s, d_descs, d_tiles,
 		                   static_cast<const U *>(d_vals), d_validity, null_bits, d_words);
+		return hipGetLastError();
+	});
+}
+
+hipError_t launch_analyze_packed(hipStream_t s, uint32_t type_size, bool sign_extend, uint64_t null_bits, int rule,
+                                 const adac_segment_desc *d_src_descs, const TileRef *d_tiles, uint64_t ntiles,
+                                 const uint64_t *d_src_words, const uint64_t *d_validity, uint64_t *d_minmax) {
+	if (ntiles == 0) return hipSuccess;
+	return dispatch_size(type_size, [&](auto tag) {
+		using U = decltype(tag);
+		hipLaunchKernelGGL(k_analyze_packed<U>, dim3((unsigned)ntiles), dim3(kWorkgroup), 0, s, d_src_descs, d_tiles,
+		                   d_src_words, d_validity, sign_extend ? 1 : 0, null_bits, rule, d_minmax);
+		return hipGetLastError();
+	});
+}
+
+hipError_t launch_repack(hipStream_t s, uint32_t type_size, uint64_t null_bits, const adac_segment_desc *d_src_descs,
+                         const adac_segment_desc *d_dst_descs, const TileRef *d_tiles, uint64_t ntiles,
+                         const uint64_t *d_src_words, const uint64_t *d_validity, uint64_t *d_dst_words) {
+	if (ntiles == 0) return hipSuccess;
+	return dispatch_size(type_size, [&](auto tag) {
+		using U = decltype(tag);
+		hipLaunchKernelGGL(k_repack<U>, dim3((unsigned)ntiles), dim3(kWorkgroup), 0, s, d_src_descs, d_dst_descs,
+		                   d_tiles, d_src_words, d_validity, null_bits, d_dst_words);
 		return hipGetLastError();
 	});
 }

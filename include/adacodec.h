@@ -210,6 +210,22 @@ adac_status adac_pack(adac_layout *l, const void *d_vals, const uint64_t *d_vali
 adac_status adac_encode(adac_layout *l, const void *d_vals, const uint64_t *d_validity, int rule, int pad_to_byte,
                         uint64_t *d_words);
 
+/* Re-compaction packed -> packed (the `adac_repack(words, n, old_w, new_w, min)` of SURVEY.md §8b; traffic
+ * n (old_w + new_w) / 8 bytes per segment, §8d).  The reference's BitCompressFromSuccinct
+ * (column_segment.cpp:348-383) re-packs in place from full-width slots; here the source is any encoded form
+ * (padded, wider than needed after the value range shrank, or unpacked slots) and the destination is a second
+ * layout over the SAME segments (type, counts, value offsets), out of place:
+ *   adac_analyze_packed  min/max of the decoded values under `rule`, left in dst for adac_plan(dst, ...);
+ *   adac_repack          decode at src's width/min, subtract dst's min, pack at dst's width into d_dst_words;
+ *   adac_reencode        analyze_packed + adac_plan(dst) + repack.
+ * The result is bit-identical to adac_encode of the decoded values.  d_validity as for adac_analyze / adac_pack. */
+adac_status adac_analyze_packed(adac_layout *src, const uint64_t *d_src_words, const uint64_t *d_validity, int rule,
+                                adac_layout *dst);
+adac_status adac_repack(adac_layout *src, const uint64_t *d_src_words, const uint64_t *d_validity, adac_layout *dst,
+                        uint64_t *d_dst_words);
+adac_status adac_reencode(adac_layout *src, const uint64_t *d_src_words, const uint64_t *d_validity, int rule,
+                          int pad_to_byte, adac_layout *dst, uint64_t *d_dst_words);
+
 /* Decode every segment: out[val_off + i] = T(read_int(words, i*w, w) + min).  Replaces SuccinctScanPartial
  * over a whole column (succinct.cpp:123-144) and ColumnSegment::UncompressSuccinct (column_segment.cpp:458-506).
  * Unpacked segments are copied without the min add (SURVEY.md §8a parity domain (iii)).
