@@ -196,20 +196,104 @@ static idx_t CodecFinalizeAppend(ColumnSegment &segment) {
 	return segment.count * segment.type_size; // succinct.cpp:324-330
 }
 
+// FixedSizeInitAnalyze / FixedSizeAnalyze / FixedSizeFinalAnalyze<T> (fixed_size_uncompressed.cpp:20-41): the
+// succinct codec borrows them unchanged (succinct.cpp:337-338) — the score is the uncompressed size.
+struct FixedSizeAnalyzeState : public AnalyzeState {
+	idx_t count = 0;
+	idx_t type_size = 0;
+};
+static std::unique_ptr<AnalyzeState> FixedSizeInitAnalyze(PhysicalType type) {
+	auto state = std::unique_ptr<FixedSizeAnalyzeState>(new FixedSizeAnalyzeState());
+	state->type_size = adac_type_size((int)type);
+	return std::move(state);
+}
+static bool FixedSizeAnalyze(AnalyzeState &state_p, Vector &, idx_t count) {
+	static_cast<FixedSizeAnalyzeState &>(state_p).count += count;
+	return true;
+}
+static idx_t FixedSizeFinalAnalyze(AnalyzeState &state_p) {
+	auto &state = static_cast<FixedSizeAnalyzeState &>(state_p);
+	return state.type_size * state.count;
+}
+
+// SuccinctCompressState and its three slots (succinct.cpp:52-119; UncompressedFunctions for the other codec)
+ColumnDataCheckpointer::ColumnDataCheckpointer(DatabaseInstance &db_p, PhysicalType type_p, idx_t row_group_start_p)
+    : db(db_p), type(type_p), row_group_start(row_group_start_p) {
+}
+ColumnDataCheckpointer::~ColumnDataCheckpointer() = default;
+
+struct SuccinctCompressState : public CompressionState {
+	explicit SuccinctCompressState(ColumnDataCheckpointer &checkpointer_p) : checkpointer(checkpointer_p) {
+		CreateEmptySegment(checkpointer.row_group_start);
+	}
+	void CreateEmptySegment(idx_t row_start) {
+		current_segment = ColumnSegment::CreateTransientSegment(checkpointer.db, checkpointer.type, row_start);
+	}
+	void FlushSegment(idx_t segment_size) {
+		checkpointer.flushed_sizes.push_back(segment_size);
+		checkpointer.flushed_segments.push_back(std::move(current_segment));
+	}
+	void Finalize(idx_t segment_size) {
+		FlushSegment(segment_size);
+		current_segment.reset();
+	}
+	ColumnDataCheckpointer &checkpointer;
+	std::unique_ptr<ColumnSegment> current_segment;
+};
+static std::unique_ptr<CompressionState> InitCompression(ColumnDataCheckpointer &checkpointer,
+                                                         std::unique_ptr<AnalyzeState>) {
+	return std::unique_ptr<CompressionState>(new SuccinctCompressState(checkpointer));
+}
+static void Compress(CompressionState &state_p, Vector &data, idx_t count) {
+	auto &state = static_cast<SuccinctCompressState &>(state_p);
+	UnifiedVectorFormat vdata; // data.ToUnifiedFormat(count, vdata)
+	vdata.data = data.data;
+	vdata.validity = data.validity;
+	idx_t offset = 0;
+	while (count > 0) {
+		idx_t appended = state.current_segment->Append(vdata, offset, count);
+		if (appended == count) return; // appended everything: finished
+		auto next_start = state.current_segment->start + state.current_segment->count;
+		state.FlushSegment(state.current_segment->FinalizeAppend()); // the segment is full
+		state.CreateEmptySegment(next_start);
+		offset += appended;
+		count -= appended;
+	}
+}
+static void FinalizeCompress(CompressionState &state_p) {
+	auto &state = static_cast<SuccinctCompressState &>(state_p);
+	state.Finalize(state.current_segment->FinalizeAppend());
+}
+
+// FixedSizeInitScan / SuccinctInitAppend pin the segment's block (fixed_size_uncompressed.cpp:125-130,
+// succinct.cpp:264-269); here the bits are owned by the segment / the pool arena, so the states carry nothing.
+static std::unique_ptr<SegmentScanState> CodecInitScan(ColumnSegment &) {
+	return std::unique_ptr<SegmentScanState>(new SegmentScanState());
+}
+static std::unique_ptr<CompressionAppendState> CodecInitAppend(ColumnSegment &) {
+	return std::unique_ptr<CompressionAppendState>(new CompressionAppendState());
+}
+
 bool SuccinctFun::TypeIsSupported(PhysicalType type) {
 	return adac_type_is_supported((int)type) != 0;
 }
 
+static CompressionFunction MakeFunction(CompressionType type, PhysicalType data_type) {
+	return CompressionFunction {type,           data_type,        FixedSizeInitAnalyze, FixedSizeAnalyze,
+	                            FixedSizeFinalAnalyze, InitCompression, Compress,        FinalizeCompress,
+	                            CodecInitScan,  CodecScan,        CodecScanPartial,     CodecFetchRow,
+	                            EmptySkip,      nullptr,          CodecInitAppend,      CodecAppend,
+	                            CodecFinalizeAppend, nullptr};
+}
+
 CompressionFunction SuccinctFun::GetFunction(PhysicalType data_type) {
 	if (!TypeIsSupported(data_type)) throw InternalException("Unsupported type for FixedSizeSuccinct::GetFunction");
-	return CompressionFunction {CompressionType::COMPRESSION_SUCCINCT, data_type, CodecScan, CodecScanPartial,
-	                            CodecFetchRow, EmptySkip, CodecAppend, CodecFinalizeAppend};
+	return MakeFunction(CompressionType::COMPRESSION_SUCCINCT, data_type);
 }
 
 CompressionFunction UncompressedFun::GetFunction(PhysicalType data_type) {
 	if (!SuccinctFun::TypeIsSupported(data_type)) throw InternalException("Unsupported type for FixedSizeUncompressed");
-	return CompressionFunction {CompressionType::COMPRESSION_UNCOMPRESSED, data_type, CodecScan, CodecScanPartial,
-	                            CodecFetchRow, EmptySkip, CodecAppend, CodecFinalizeAppend};
+	return MakeFunction(CompressionType::COMPRESSION_UNCOMPRESSED, data_type);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -820,6 +904,62 @@ extern "C" adach_segment *adach_segment_create(adach_db *h, int physical_type, u
 		s = new adach_segment {std::move(seg)};
 	});
 	return s;
+}
+
+extern "C" int adach_compress_column(adach_db *h, int compression_type, int physical_type, uint64_t row_group_start,
+                                     const void *values, const uint64_t *validity, uint64_t n,
+                                     adach_segment **out_segments, uint64_t max_segments, uint64_t *out_nseg,
+                                     uint64_t *out_sizes, uint64_t *out_score) {
+	return Guard([&]() {
+		// the checkpoint pipeline of ColumnDataCheckpointer::WriteToDisk (column_data_checkpointer.cpp): analyze
+		// every vector, score, then compress every vector through the winning function's slots
+		auto type = (PhysicalType)physical_type;
+		const CompressionFunction *fn = h->db->GetCompressionFunction((CompressionType)compression_type, type);
+		const idx_t tsize = adac_type_size(physical_type);
+		auto astate = fn->init_analyze(type);
+		for (idx_t off = 0; off < n; off += STANDARD_VECTOR_SIZE) {
+			idx_t c = std::min<idx_t>(STANDARD_VECTOR_SIZE, n - off);
+			Vector v;
+			v.data = (data_ptr_t)values + off * tsize;
+			if (!fn->analyze(*astate, v, c)) throw InternalException("analyze refused the column");
+		}
+		if (out_score) *out_score = fn->final_analyze(*astate);
+		ColumnDataCheckpointer checkpointer(*h->db, type, row_group_start);
+		auto cstate = fn->init_compression(checkpointer, std::move(astate));
+		std::vector<uint64_t> shifted;
+		for (idx_t off = 0; off < n; off += STANDARD_VECTOR_SIZE) {
+			idx_t c = std::min<idx_t>(STANDARD_VECTOR_SIZE, n - off);
+			Vector v;
+			v.data = (data_ptr_t)values + off * tsize;
+			if (validity) { // the vector's own mask starts at its first row (2048 | 64: whole words)
+				v.validity = validity + off / 64;
+			}
+			fn->compress(*cstate, v, c);
+		}
+		fn->compress_finalize(*cstate);
+		if (checkpointer.flushed_segments.size() > max_segments) throw InternalException("segment array too small");
+		*out_nseg = checkpointer.flushed_segments.size();
+		for (size_t i = 0; i < checkpointer.flushed_segments.size(); i++) {
+			out_segments[i] = new adach_segment {std::move(checkpointer.flushed_segments[i])};
+			if (out_sizes) out_sizes[i] = checkpointer.flushed_sizes[i];
+		}
+	});
+}
+
+extern "C" int adach_function_slots(adach_db *h, int compression_type, int physical_type, int *present) {
+	return Guard([&]() {
+		const CompressionFunction *fn =
+		    h->db->GetCompressionFunction((CompressionType)compression_type, (PhysicalType)physical_type);
+		const void *slots[16] = {(const void *)fn->init_analyze, (const void *)fn->analyze,
+		                         (const void *)fn->final_analyze, (const void *)fn->init_compression,
+		                         (const void *)fn->compress, (const void *)fn->compress_finalize,
+		                         (const void *)fn->init_scan, (const void *)fn->scan_vector,
+		                         (const void *)fn->scan_partial, (const void *)fn->fetch_row,
+		                         (const void *)fn->skip, (const void *)fn->init_segment,
+		                         (const void *)fn->init_append, (const void *)fn->append,
+		                         (const void *)fn->finalize_append, (const void *)fn->revert_append};
+		for (int i = 0; i < 16; i++) present[i] = slots[i] != nullptr;
+	});
 }
 
 extern "C" void adach_segment_destroy(adach_segment *s) {

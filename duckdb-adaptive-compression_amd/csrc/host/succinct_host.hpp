@@ -71,6 +71,7 @@ struct UnifiedVectorFormat {
 struct Vector {
 	data_ptr_t data = nullptr;
 	bool flat = true;
+	const uint64_t *validity = nullptr; // read by the compress slot (Vector::ToUnifiedFormat); nullptr = all valid
 };
 
 struct ColumnScanState {
@@ -82,19 +83,57 @@ class ColumnSegment;
 class ColumnSegmentCatalog;
 class DatabaseInstance;
 
-// The function-pointer table (compression_function.hpp:105-177), scan/append half: the checkpoint-side slots
-// (init_analyze .. compress_finalize) do not exist for an in-memory codec (succinct.cpp:91-119 prints
-// "SHOULD NOT HAPPEN").
+// States the slots hand back to the engine (compression_function.hpp:29-63): owned by the caller, virtual dtors.
+struct AnalyzeState {
+	virtual ~AnalyzeState() = default;
+};
+struct CompressionState {
+	virtual ~CompressionState() = default;
+};
+struct SegmentScanState {
+	virtual ~SegmentScanState() = default;
+};
+struct CompressionAppendState {
+	virtual ~CompressionAppendState() = default;
+};
+
+// The slice of duckdb::ColumnDataCheckpointer the compress slots use (GetDatabase, GetType, GetRowGroup().start,
+// GetCheckpointState().FlushSegment): flushed segments are collected here in order.
+struct ColumnDataCheckpointer {
+	ColumnDataCheckpointer(DatabaseInstance &db, PhysicalType type, idx_t row_group_start);
+	~ColumnDataCheckpointer();
+	DatabaseInstance &db;
+	PhysicalType type;
+	idx_t row_group_start;
+	std::vector<std::unique_ptr<ColumnSegment>> flushed_segments;
+	std::vector<idx_t> flushed_sizes; // the segment_size argument of FlushSegment (bytes used)
+};
+
+// The function-pointer table (compression_function.hpp:105-177), all sixteen slots in the reference's order as
+// SuccinctGetFunction fills them (succinct.cpp:335-343): analyze borrowed from FixedSize*, the checkpoint-side
+// compress slots append into transient segments (the reference prints "SHOULD NOT HAPPEN" there but wires them),
+// init_segment and revert_append are nullptr.
 struct CompressionFunction {
 	CompressionType type;
 	PhysicalType data_type;
+	std::unique_ptr<AnalyzeState> (*init_analyze)(PhysicalType type);
+	bool (*analyze)(AnalyzeState &state, Vector &input, idx_t count);
+	idx_t (*final_analyze)(AnalyzeState &state);
+	std::unique_ptr<CompressionState> (*init_compression)(ColumnDataCheckpointer &checkpointer,
+	                                                     std::unique_ptr<AnalyzeState> state);
+	void (*compress)(CompressionState &state, Vector &scan_vector, idx_t count);
+	void (*compress_finalize)(CompressionState &state);
+	std::unique_ptr<SegmentScanState> (*init_scan)(ColumnSegment &segment);
 	void (*scan_vector)(ColumnSegment &segment, ColumnScanState &state, idx_t scan_count, Vector &result);
 	void (*scan_partial)(ColumnSegment &segment, ColumnScanState &state, idx_t scan_count, Vector &result,
 	                     idx_t result_offset);
 	void (*fetch_row)(ColumnSegment &segment, ColumnFetchState &state, row_t row_id, Vector &result, idx_t result_idx);
 	void (*skip)(ColumnSegment &segment, ColumnScanState &state, idx_t skip_count);
+	void *(*init_segment)(ColumnSegment &segment, int64_t block_id); // nullptr for both codecs
+	std::unique_ptr<CompressionAppendState> (*init_append)(ColumnSegment &segment);
 	idx_t (*append)(ColumnSegment &segment, UnifiedVectorFormat &data, idx_t offset, idx_t count);
 	idx_t (*finalize_append)(ColumnSegment &segment);
+	void (*revert_append)(ColumnSegment &segment, idx_t start_row); // nullptr for both codecs
 };
 
 struct SuccinctFun {

@@ -19,6 +19,9 @@ HOST_SIGNATURES = {
     "adach_full_scan": (_int, [C.POINTER(_vp), _u64, _u64, C.POINTER(_u64), C.POINTER(C.c_double), C.POINTER(_u64)]),
     "adach_db_data_size": (_i64, [_vp]),
     "adach_db_arena_used_bytes": (_u64, [_vp]),
+    "adach_compress_column": (_int, [_vp, _int, _int, _u64, _vp, _vp, _u64, C.POINTER(_vp), _u64, C.POINTER(_u64),
+                                     C.POINTER(_u64), C.POINTER(_u64)]),
+    "adach_function_slots": (_int, [_vp, _int, _int, C.POINTER(_int)]),
     "adach_segment_create": (_vp, [_vp, _int, _u64, _u64]),
     "adach_segment_destroy": (None, [_vp]),
     "adach_segment_append": (_i64, [_vp, _vp, _vp, _vp, _u64, _u64]),
@@ -100,6 +103,38 @@ class Database:
         s = Segment(self, dtype, start, segment_size)
         self.segments.append(s)
         return s
+
+    SLOT_NAMES = ("init_analyze", "analyze", "final_analyze", "init_compression", "compress", "compress_finalize",
+                  "init_scan", "scan_vector", "scan_partial", "fetch_row", "skip", "init_segment", "init_append",
+                  "append", "finalize_append", "revert_append")
+
+    def function_slots(self, dtype, compression_type=10):
+        """Which slots of duckdb::CompressionFunction the table fills (10 = SUCCINCT, 1 = UNCOMPRESSED)."""
+        present = (_int * 16)()
+        _ok(hlib().adach_function_slots(self._h, compression_type, physical_type(dtype), present), "function_slots")
+        return {n: bool(p) for n, p in zip(self.SLOT_NAMES, present)}
+
+    def compress_column(self, values, validity=None, row_group_start=0, compression_type=10):
+        """The checkpoint-side slots over a whole column (analyze every vector, score, compress every vector).
+        Returns (segments, bytes reported per segment, analyze score)."""
+        values = np.ascontiguousarray(values)
+        if validity is not None:
+            validity = np.ascontiguousarray(validity, dtype=np.uint64)
+        cap = len(values) // 2048 + 8
+        arr = (_vp * cap)()
+        sizes = (_u64 * cap)()
+        nseg, score = _u64(), _u64()
+        _ok(hlib().adach_compress_column(self._h, compression_type, physical_type(values.dtype), row_group_start,
+                                         _p(values), _p(validity), len(values), arr, cap, C.byref(nseg), sizes,
+                                         C.byref(score)), "compress_column")
+        segs, row = [], row_group_start
+        for i in range(nseg.value):
+            s = Segment.__new__(Segment)
+            s.db, s.dtype, s.start, s._h = self, values.dtype, row, arr[i]
+            row += s.count
+            segs.append(s)
+            self.segments.append(s)
+        return segs, [sizes[i] for i in range(nseg.value)], score.value
 
     def cache_stats(self):
         h, m, b = _u64(), _u64(), _u64()

@@ -45,6 +45,20 @@ void adach_db_destroy(adach_db *db);
 int64_t adach_db_data_size(adach_db *db);          /* BufferManager::GetDataSize analogue */
 uint64_t adach_db_arena_used_bytes(adach_db *db);  /* HBM actually held by packed segments */
 
+/* The checkpoint-side half of the plugin table (compression_function.hpp:65-103), driven the way
+ * ColumnDataCheckpointer does: init_analyze / analyze (every 2048-row vector) / final_analyze -> *out_score, then
+ * init_compression / compress (every vector) / compress_finalize (succinct.cpp:52-119: CreateEmptySegment,
+ * Append until full, FlushSegment).  compression_type: 10 = SUCCINCT, 1 = UNCOMPRESSED.  The flushed segments are
+ * returned in order (caller destroys them); out_sizes[i] = bytes FinalizeAppend reported for segment i. */
+int adach_compress_column(adach_db *db, int compression_type, int physical_type, uint64_t row_group_start,
+                          const void *values, const uint64_t *validity, uint64_t n, adach_segment **out_segments,
+                          uint64_t max_segments, uint64_t *out_nseg, uint64_t *out_sizes, uint64_t *out_score);
+/* present[0..15] = which of the sixteen slots the function table fills, in the reference's order (init_analyze,
+ * analyze, final_analyze, init_compression, compress, compress_finalize, init_scan, scan_vector, scan_partial,
+ * fetch_row, skip, init_segment, init_append, append, finalize_append, revert_append): succinct.cpp:335-343 leaves
+ * init_segment and revert_append null. */
+int adach_function_slots(adach_db *db, int compression_type, int physical_type, int *present);
+
 adach_segment *adach_segment_create(adach_db *db, int physical_type, uint64_t start, uint64_t segment_size);
 void adach_segment_destroy(adach_segment *seg);
 /* returns rows consumed (the caller opens a new segment for the rest), -1 on error */

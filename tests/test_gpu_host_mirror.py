@@ -327,3 +327,51 @@ def test_decoded_segment_cache_serves_vectors(adac, host):
         assert small.cache_stats()["bytes"] <= 300_000
     finally:
         small.close()
+
+
+def test_all_sixteen_plugin_slots_and_the_checkpoint_side_pipeline(adac, oracle, host):
+    """succinct.cpp:335-343: FixedSize analyze slots, InitCompression / Compress / FinalizeCompress, init_scan,
+    scans, fetch_row, EmptySkip, init_append / append / finalize_append; init_segment and revert_append are null.
+    The compress slots fill BLOCK_SIZE segments (CreateEmptySegment -> Append until full -> FlushSegment) and each
+    full segment compacts itself as it fills (column_segment.cpp:266-268)."""
+    db = host.Database(0, succinct_enabled=True, adaptive=False, arena_bytes=64 << 20)
+    for ctype in (10, 1):
+        slots = db.function_slots(np.uint32, ctype)
+        assert [n for n, p in slots.items() if not p] == ["init_segment", "revert_append"]
+    with pytest.raises(adac.AdacError):
+        db.function_slots(np.float32)   # InternalException("Unsupported type ...") territory (succinct.cpp:364)
+    n = 200_000
+    vals = (np.arange(n, dtype=np.uint32) * 3 + 1000)
+    segs, sizes, score = db.compress_column(vals, row_group_start=122_880)
+    assert score == 4 * n                                     # FixedSizeFinalAnalyze<T>: sizeof(T) * count
+    per = 262_136 // 4
+    counts = [per, per, per, n - 3 * per]
+    assert [s.count for s in segs] == counts and sizes == [4 * c for c in counts]
+    assert [s.start for s in segs] == [122_880 + sum(counts[:i]) for i in range(4)]
+    row = 0
+    for s, c in zip(segs, counts):
+        o = oracle.Segment(np.uint32, segment_size=262_136, store_min=True)
+        off = 0
+        while off < c:   # the oracle segment fed the same vectors
+            k = min(2048 - (row + off) % 2048, c - off)
+            o.append(vals[row:row + c], None, offset=off, count=k)
+            off += k
+        if c == per:
+            assert s.compacted and s.width == o.width and s.min_factor == o.min_factor
+            assert s.data_size == o.data_size
+        got = np.concatenate([s.scan(r, min(2048, c - r)) for r in range(0, c, 2048)])
+        assert np.array_equal(got, vals[row:row + c])
+        row += c
+    # NULLs through the compress slot (Vector::ToUnifiedFormat hands the vector's own validity mask on)
+    valid = np.ones(n, dtype=bool)
+    valid[5::7] = False
+    vm = np.packbits(valid, bitorder="little")
+    vm = np.concatenate([vm, np.zeros((-len(vm)) % 8 + 8, np.uint8)]).view(np.uint64)
+    segs2, _, _ = db.compress_column(vals.astype(np.int32) - 500_000, validity=vm)
+    row = 0
+    for s in segs2:
+        got = np.concatenate([s.scan(r, min(2048, s.count - r)) for r in range(0, s.count, 2048)])
+        ok = valid[row:row + s.count]
+        assert np.array_equal(got[ok], (vals.astype(np.int32) - 500_000)[row:row + s.count][ok])
+        row += s.count
+    db.close()
