@@ -279,6 +279,12 @@ def main():
     col.encode(adac.RULE_APPEND)
     ctx.sync()
     enc_ms = time_launches(ctx, lambda: col.encode(adac.RULE_APPEND), 10)
+    # A2 alone: the append path carries min/max (succinct.cpp:286-299), so Compact() is width decision + one pack pass
+
+    def plan_pack():
+        col.layout.plan(adac.RULE_APPEND, False)
+        col.layout.pack(col.d_vals, col.d_words)
+    pack_ms = time_launches(ctx, plan_pack, 10)
     descs = col.fetch_descs()
     rd, wr, meta = algorithmic_bytes(descs, dtype.itemsize)
     wh = {}
@@ -365,7 +371,13 @@ def main():
     result["encode"] = {
         "values_per_s": args.rows / (enc_ms * 1e-3), "ms": enc_ms,
         "algorithmic_GBps": (2 * wr + rd) / (enc_ms * 1e-3) / 1e9,
-        "note": "analyze + plan + pack, raw column read twice (min/max pass, pack pass)",
+        "note": "analyze + plan + pack, raw column read twice (min/max pass, pack pass): BitCompressFromUncompressed's "
+                "two passes (column_segment.cpp:385-456)",
+        "compact_after_append": {
+            "ms": pack_ms, "values_per_s": args.rows / (pack_ms * 1e-3),
+            "algorithmic_GBps": (wr + rd) / (pack_ms * 1e-3) / 1e9,
+            "note": "plan + pack with the min/max the append path carries: BitCompressFromSuccinct "
+                    "(column_segment.cpp:348-383)"},
     }
 
     if world == 1 and rank == 0:

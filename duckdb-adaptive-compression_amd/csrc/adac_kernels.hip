@@ -972,9 +972,13 @@ constexpr int kPlanThreads = 1024;
 __global__ __launch_bounds__(kPlanThreads) void k_plan(adac_segment_desc *__restrict__ descs,
                                                        const uint64_t *__restrict__ minmax, uint64_t nseg,
                                                        uint32_t type_bits, int rule, int pad) {
-	__shared__ uint64_t scan[kPlanThreads];
-	__shared__ uint64_t carry;
-	if (threadIdx.x == 0) carry = 0;
+	// exclusive scan of the segments' arena footprints: wave64 shuffle scan, the 16 wave totals through LDS,
+	// a running carry across chunks of 1024 segments — two barriers per chunk
+	constexpr int kWaves = kPlanThreads / 64;
+	__shared__ uint64_t wave_total[kWaves];
+	__shared__ uint64_t carry_s;
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	if (threadIdx.x == 0) carry_s = 0;
 	__syncthreads();
 	for (uint64_t base = 0; base < nseg; base += kPlanThreads) {
 		const uint64_t s = base + threadIdx.x;
@@ -993,23 +997,25 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan(adac_segment_desc *__rest
 			const uint64_t bits = (uint64_t)descs[s].count * w;
 			fp = (((bits + 64) >> 6) + 15) & ~15ull; // SDSL allocation, rounded to 128 B
 		}
-		scan[threadIdx.x] = fp;
-		__syncthreads();
-		for (int off = 1; off < kPlanThreads; off <<= 1) { // Hillis-Steele inclusive scan
-			uint64_t v = threadIdx.x >= (uint32_t)off ? scan[threadIdx.x - off] : 0;
-			__syncthreads();
-			scan[threadIdx.x] += v;
-			__syncthreads();
+		uint64_t incl = fp;
+#pragma unroll
+		for (int off = 1; off < 64; off <<= 1) {
+			const uint64_t up = __shfl_up(incl, off, 64);
+			if (lane >= (uint32_t)off) incl += up;
 		}
+		if (lane == 63) wave_total[wave] = incl;
+		__syncthreads();
+		uint64_t before = carry_s;
+		for (uint32_t i = 0; i < wave; i++) before += wave_total[i];
 		if (s < nseg) {
-			descs[s].word_off = carry + scan[threadIdx.x] - fp;
+			descs[s].word_off = before + incl - fp;
 			descs[s].min = mn;
 			descs[s].width = (uint8_t)w;
 			descs[s].flags = flags;
 			descs[s].reserved = 0;
 		}
 		__syncthreads();
-		if (threadIdx.x == kPlanThreads - 1) carry += scan[threadIdx.x];
+		if (threadIdx.x == kPlanThreads - 1) carry_s = before + incl;
 		__syncthreads();
 	}
 }
