@@ -81,24 +81,102 @@ __global__ void k_bp_prepare(BpGroup *__restrict__ groups, uint64_t ngroups, con
 	groups[i] = g;
 }
 
-// Coalesced copy of `n` rows from an LDS array to out[0..n), 16-byte stores aligned on the output address.
+// Inclusive wave64 prefix sum in registers with DPP (no LDS round trips: a ds_bpermute-based __shfl_up scan is a
+// chain of six ~100-cycle dependent steps).  row_shr:1/2/4/8 scan each row of 16 lanes (lanes without a source
+// get 0), row_bcast:15 adds row totals into rows 1 and 3, row_bcast:31 adds lane 31's total into rows 2 and 3.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v) {
+	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint64_t dpp_step(uint64_t v) {
+	const uint32_t lo = dpp_or_zero<CTRL, ROW_MASK>((uint32_t)v);
+	const uint32_t hi = dpp_or_zero<CTRL, ROW_MASK>((uint32_t)(v >> 32));
+	return v + (((uint64_t)hi << 32) | lo);
+}
+
 template <typename U>
-__device__ __forceinline__ void store_rows_from_lds(const U *lds_vals, U *dst, uint32_t n) {
-	constexpr int K = 16 / (int)sizeof(U);
-	const uint32_t align = (uint32_t)((reinterpret_cast<uintptr_t>(dst) / sizeof(U)) & (K - 1));
-	for (uint32_t c = threadIdx.x; c * K < n + align; c += kWorkgroup) {
-		const int32_t base = (int32_t)(c * K) - (int32_t)align;
-		if (base >= 0 && (uint32_t)(base + K) <= n) {
-			U v[K];
+__device__ __forceinline__ U wave_inclusive_sum(U x) {
+	if (sizeof(U) == 8) {
+		uint64_t v = (uint64_t)x;
+		v = dpp_step<0x111, 0xf>(v); // row_shr:1
+		v = dpp_step<0x112, 0xf>(v); // row_shr:2
+		v = dpp_step<0x114, 0xf>(v); // row_shr:4
+		v = dpp_step<0x118, 0xf>(v); // row_shr:8
+		v = dpp_step<0x142, 0xa>(v); // row_bcast:15 -> rows 1, 3
+		v = dpp_step<0x143, 0xc>(v); // row_bcast:31 -> rows 2, 3
+		return (U)v;
+	}
+	uint32_t v = (uint32_t)x; // narrower T: sums wrap mod 2^bits, which truncation preserves
+	v += dpp_or_zero<0x111, 0xf>(v);
+	v += dpp_or_zero<0x112, 0xf>(v);
+	v += dpp_or_zero<0x114, 0xf>(v);
+	v += dpp_or_zero<0x118, 0xf>(v);
+	v += dpp_or_zero<0x142, 0xa>(v);
+	v += dpp_or_zero<0x143, 0xc>(v);
+	return (U)v;
+}
+
+template <typename U>
+struct BpScan {
+	static constexpr int K = 16 / (int)sizeof(U);
+	// rounds of 256 chunks that cover one metadata group plus an output misalignment of up to K - 1 rows
+	static constexpr int ROUNDS = (kBpGroupRows + K - 1 + kWorkgroup * K - 1) / (kWorkgroup * K);
+};
+
+template <typename U, bool WIDE>
+__device__ __forceinline__ void bp_delta_scan(const uint32_t *lds32, uint32_t bit0, uint32_t w, uint64_t frame,
+                                              U delta_offset, uint32_t n, uint32_t align, U *__restrict__ dst,
+                                              U (*wave_tot)[kWorkgroup / 64]) {
+	constexpr int K = BpScan<U>::K;
+	constexpr int ROUNDS = BpScan<U>::ROUNDS;
+	constexpr int WAVES = kWorkgroup / 64;
+	const uint32_t mlo = WIDE ? 0xffffffffu : mask32(w);
+	const uint32_t mhi = WIDE ? mask32(w - 32u) : 0u;
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	// every round's chunk is decoded and scanned before the single barrier, so the rounds overlap instead of
+	// waiting on each other's carries; rows outside [0, n) contribute zero and store nothing
+	U v[ROUNDS][K], run[ROUNDS], incl[ROUNDS];
 #pragma unroll
-			for (int j = 0; j < K; j++) v[j] = lds_vals[base + j];
+	for (int r = 0; r < ROUNDS; r++) {
+		const int32_t base = (int32_t)((r * kWorkgroup + threadIdx.x) * K) - (int32_t)align;
+		U acc = 0;
+#pragma unroll
+		for (int j = 0; j < K; j++) {
+			const uint32_t row = (uint32_t)(base + j); // rows < 0 wrap to huge values: out of range
+			uint32_t lo, hi;
+			read_field<WIDE>(lds32, bit0 + (row < n ? row : 0u) * w, mlo, mhi, lo, hi);
+			const U d = sizeof(U) == 8 ? (U)((((uint64_t)hi << 32) | lo) + frame) : (U)(lo + (uint32_t)frame);
+			acc = (U)(acc + (row < n ? d : (U)0));
+			v[r][j] = acc;
+		}
+		run[r] = acc;
+		incl[r] = wave_inclusive_sum<U>(acc); // inclusive scan of the lane totals inside the wave
+		if (lane == 63) wave_tot[r][wave] = incl[r];
+	}
+	__syncthreads();
+	U carry = delta_offset;
+#pragma unroll
+	for (int r = 0; r < ROUNDS; r++) {
+		U before = carry;
+#pragma unroll
+		for (int wv = 0; wv < WAVES; wv++) {
+			const U t = wave_tot[r][wv];
+			if ((uint32_t)wv < wave) before = (U)(before + t);
+			carry = (U)(carry + t);
+		}
+		before = (U)(before + (U)(incl[r] - run[r]));
+		const int32_t base = (int32_t)((r * kWorkgroup + threadIdx.x) * K) - (int32_t)align;
+#pragma unroll
+		for (int j = 0; j < K; j++) v[r][j] = (U)(v[r][j] + before);
+		if (base >= 0 && (uint32_t)(base + K) <= n) {
 			uint4 q;
-			__builtin_memcpy(&q, v, 16);
+			__builtin_memcpy(&q, v[r], 16);
 			*reinterpret_cast<uint4 *>(dst + base) = q;
 		} else {
 #pragma unroll
 			for (int j = 0; j < K; j++) {
-				if ((uint32_t)(base + j) < n) dst[base + j] = lds_vals[base + j];
+				if ((uint32_t)(base + j) < n) dst[base + j] = v[r][j];
 			}
 		}
 	}
@@ -108,8 +186,7 @@ template <typename U>
 __global__ __launch_bounds__(kWorkgroup) void k_bp_unpack(const BpGroup *__restrict__ groups,
                                                           const uint8_t *__restrict__ blocks, U *__restrict__ out) {
 	__shared__ uint4 lds[kTileBytes / 16 + 2];
-	__shared__ __attribute__((aligned(16))) U vals[kBpGroupRows];
-	__shared__ U wave_tot[kWorkgroup / 64];
+	__shared__ U wave_tot[BpScan<U>::ROUNDS][kWorkgroup / 64];
 	const BpGroup g = groups[blockIdx.x];
 	BpHeader h;
 	h.mode = g.mode;
@@ -155,48 +232,14 @@ __global__ __launch_bounds__(kWorkgroup) void k_bp_unpack(const BpGroup *__restr
 	}
 
 	// DELTA_FOR: v[i] = delta_offset + sum_{j<=i} (field[j] + for), wrapping in T (bitpacking.cpp:810-813).
-	// fields + for -> LDS; each lane scans 8 consecutive rows, lanes and waves are chained by a shuffle scan.
-	auto to_lds = [&](int32_t base, const U *v, bool full) {
-		constexpr int KK = 16 / (int)sizeof(U);
-#pragma unroll
-		for (int j = 0; j < KK; j++) {
-			if (full || (uint32_t)(base + j) < n) vals[base + j] = v[j];
-		}
-	};
+	// A lane decodes the K consecutive rows of one 16-byte output chunk into registers and scans them; lanes are
+	// chained by a wave64 shuffle scan, waves by four totals through LDS (double-buffered: one barrier per round of
+	// 256 chunks), rounds by a running carry.  The values never visit LDS and leave with 16-byte stores.
 	if (sizeof(U) == 8 && w > 32) {
-		decode_rows<U, true>(lds32, bit0, w, h.frame, n, 0u, to_lds);
+		bp_delta_scan<U, true>(lds32, bit0, w, h.frame, (U)h.extra, n, align, dst, wave_tot);
 	} else {
-		decode_rows<U, false>(lds32, bit0, w, h.frame, n, 0u, to_lds);
+		bp_delta_scan<U, false>(lds32, bit0, w, h.frame, (U)h.extra, n, align, dst, wave_tot);
 	}
-	__syncthreads();
-	constexpr int PER = kBpGroupRows / kWorkgroup; // 8 consecutive rows per lane
-	U loc[PER];
-	U run = 0;
-#pragma unroll
-	for (int k = 0; k < PER; k++) {
-		const uint32_t r = threadIdx.x * PER + k;
-		run = (U)(run + (r < n ? vals[r] : (U)0));
-		loc[k] = run;
-	}
-	U incl = run; // inclusive scan of the lane totals inside the wave
-	const uint32_t lane = threadIdx.x & 63u;
-#pragma unroll
-	for (int off = 1; off < 64; off <<= 1) {
-		const U up = (U)__shfl_up((unsigned long long)incl, off, 64);
-		if (lane >= (uint32_t)off) incl = (U)(incl + up);
-	}
-	if (lane == 63) wave_tot[threadIdx.x >> 6] = incl;
-	__syncthreads();
-	U carry = (U)h.extra; // delta_offset, then the totals of the waves before this one
-	for (uint32_t wv = 0; wv < (threadIdx.x >> 6); wv++) carry = (U)(carry + wave_tot[wv]);
-	carry = (U)(carry + (U)(incl - run));
-#pragma unroll
-	for (int k = 0; k < PER; k++) {
-		const uint32_t r = threadIdx.x * PER + k;
-		if (r < n) vals[r] = (U)(loc[k] + carry);
-	}
-	__syncthreads();
-	store_rows_from_lds<U>(vals, dst, n);
 }
 
 // Point fetch (BitpackingFetchRow, bitpacking.cpp:827-870): one lane per row; a DELTA_FOR row needs the prefix of
