@@ -38,8 +38,11 @@ def short(name):
             else:
                 t = ""
             extra = ""
-            if k == "k_scan_agg":
-                extra = ",sum" if ", 0>" in name else ",count_eq"
+            if k == "k_scan_agg":  # k_scan_agg<U, OP, V>: OP 0 sum, 1 count(range), 2 probe, 3 select bitmap
+                import re
+                m = re.search(r"k_scan_agg<[^,]+, (\d), (true|false)>", name)
+                op = {"0": "sum", "1": "count", "2": "probe", "3": "select"}.get(m.group(1), "?") if m else "?"
+                extra = "," + op + (",valid" if m and m.group(2) == "true" else "")
             if k == "k_unpack" and ", true>" in name:
                 extra = ",range"
             return "%s<%s%s>" % (k, t, extra) if t else k
