@@ -59,6 +59,7 @@ def adaptive(host, wl, nseg=400, rows=32767, periods=4):
     data = [((i << 34) + rng.integers(0, 1 << (10 + i % 12), size=rows)).astype(np.uint64) for i in range(nseg)]
     for skew in (0.5, 1.0, 2.0):
         db = host.Database(0, adaptive=True, arena_bytes=512 << 20)
+        db.reserve_staging(nseg * rows * 8 + (1 << 20))   # one-time page-locking kept out of the first policy round
         for i in range(nseg):
             s = db.create_segment(np.uint64, start=i * rows)
             for off in range(0, rows, 2048):

@@ -4,7 +4,10 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <string>
 
 #include "adacodec_host.h"
 
@@ -156,6 +159,26 @@ void *SegmentPool::Staging(size_t bytes) {
 void *SegmentPool::Staging2(size_t bytes) {
 	return Grow(ctx, d_staging2, staging2_bytes, bytes + 64);
 }
+
+// ADACH_TRACE=1: wall time of the phases of a batched compaction on stderr (diagnostic only).
+struct PhaseTrace {
+	bool on;
+	std::chrono::steady_clock::time_point t0;
+	std::string line;
+	PhaseTrace() : on(std::getenv("ADACH_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {
+	}
+	void mark(const char *what) {
+		if (!on) return;
+		auto t1 = std::chrono::steady_clock::now();
+		char buf[96];
+		std::snprintf(buf, sizeof buf, " %s=%.3fms", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+		line += buf;
+		t0 = t1;
+	}
+	~PhaseTrace() {
+		if (on && !line.empty()) std::fprintf(stderr, "[adach]%s\n", line.c_str());
+	}
+};
 
 // A batch layout shared by the segments compacted together (one adac_layout, many segments).
 struct LayoutHandle {
@@ -505,6 +528,7 @@ void ColumnSegment::CompactMany(DatabaseInstance &db, const std::vector<ColumnSe
 	}
 	const bool padded = db.config.succinct_padded_to_next_byte_enabled;
 	for (auto &g : groups) {
+		PhaseTrace trace;
 		const int ptype = g.first.first;
 		const int rule = g.first.second;
 		auto &segs = g.second;
@@ -542,9 +566,11 @@ void ColumnSegment::CompactMany(DatabaseInstance &db, const std::vector<ColumnSe
 		{ // device work under the pool lock; representation flips (bit_compression_lock) after it is released
 		std::lock_guard<std::mutex> pg(db.pool.lock);
 		adac_ctx *ctx = db.pool.ctx;
+		trace.mark("prep");
 		// gather the segments' rows into page-locked staging (a few host threads for big batches: the gather,
 		// not PCIe, bounds a re-compaction round) and upload them with one copy at PCIe rate
 		uint8_t *host = db.pool.PinnedStaging(host_bytes);
+		trace.mark("pinned_alloc");
 		{
 			auto gather = [&](size_t lo, size_t hi) {
 				for (size_t i = lo; i < hi; i++) {
@@ -566,8 +592,11 @@ void ColumnSegment::CompactMany(DatabaseInstance &db, const std::vector<ColumnSe
 				for (auto &t : th) t.join();
 			}
 		}
+		trace.mark("gather");
 		void *d_vals = db.pool.Staging(host_bytes);
+		trace.mark("dev_alloc");
 		Check(adac_memcpy_h2d(ctx, d_vals, host, host_bytes), "upload rows");
+		trace.mark("h2d");
 		uint64_t *d_valid = nullptr;
 		if (any_null) {
 			d_valid = static_cast<uint64_t *>(db.pool.Staging2(vmask.size() * 8));
@@ -579,6 +608,7 @@ void ColumnSegment::CompactMany(DatabaseInstance &db, const std::vector<ColumnSe
 		if (st == ADAC_OK) st = adac_layout_get_minmax(probe, mm.data());
 		adac_layout_destroy(probe);
 		Check(st, "adac_analyze");
+		trace.mark("analyze");
 		// width decision (column_segment.cpp:351-363 / :404-420) and arena placement
 		std::vector<uint32_t> pcounts;
 		std::vector<uint64_t> poffs;
@@ -605,11 +635,17 @@ void ColumnSegment::CompactMany(DatabaseInstance &db, const std::vector<ColumnSe
 			Check(adac_layout_create(ctx, ptype, pcounts.data(), poffs.data(), descs.size(), &handle->layout),
 			      "adac_layout_create");
 			Check(adac_layout_set_descs(handle->layout, descs.data()), "adac_layout_set_descs");
+			trace.mark("alloc+layout");
 			Check(adac_pack(handle->layout, d_vals, d_valid, db.pool.d_arena), "adac_pack");
 			Check(adac_ctx_sync(ctx), "adac_ctx_sync");
+			trace.mark("pack");
 		}
 		} // pool lock released
 		size_t p = 0;
+		// the unpacked images of a big batch go back to the OS off the critical path: unmapping a 256 KiB block
+		// costs ~18 us, 6.5 ms for the 360 segments of a first policy round
+		std::vector<std::vector<uint8_t>> graveyard;
+		if (segs.size() > 8) graveyard.reserve(segs.size());
 		for (size_t i = 0; i < segs.size(); i++) {
 			bool packed = p < pidx.size() && pidx[p] == i;
 			if (packed) {
@@ -617,13 +653,18 @@ void ColumnSegment::CompactMany(DatabaseInstance &db, const std::vector<ColumnSe
 				segs[i]->layout_index = p;
 			}
 			segs[i]->FinishCompaction(packed, widths[i], mm[2 * i], mm[2 * i + 1], rule,
-			                          packed ? descs[p].word_off : 0);
+			                          packed ? descs[p].word_off : 0, segs.size() > 8 ? &graveyard : nullptr);
 			if (packed) p++;
 		}
+		if (!graveyard.empty()) {
+			std::thread([g = std::move(graveyard)]() mutable { g.clear(); }).detach();
+		}
+		trace.mark("finish");
 	}
 }
 
-void ColumnSegment::FinishCompaction(bool packed, uint8_t width, uint64_t mn, uint64_t mx, int rule, uint64_t off) {
+void ColumnSegment::FinishCompaction(bool packed, uint8_t width, uint64_t mn, uint64_t mx, int rule, uint64_t off,
+                                     std::vector<std::vector<uint8_t>> *graveyard) {
 	std::lock_guard<std::mutex> g(bit_compression_lock);
 	const idx_t before = GetDataSize();
 	if (rule == ADAC_RULE_APPEND) {
@@ -643,7 +684,13 @@ void ColumnSegment::FinishCompaction(bool packed, uint8_t width, uint64_t mn, ui
 		packed_on_device = true;
 		word_off = off;
 		arena_words = adac_arena_words(count, width);
-		std::vector<uint8_t>().swap(raw); // the unpacked image is gone, as after SDSL's realloc shrink
+		// the unpacked image is gone, as after SDSL's realloc shrink
+		if (graveyard) {
+			graveyard->emplace_back(std::move(raw));
+			raw = std::vector<uint8_t>();
+		} else {
+			std::vector<uint8_t>().swap(raw);
+		}
 	}
 	std::vector<uint64_t>().swap(validity);
 	any_null = false;
@@ -943,6 +990,16 @@ extern "C" int adach_compress_column(adach_db *h, int compression_type, int phys
 			out_segments[i] = new adach_segment {std::move(checkpointer.flushed_segments[i])};
 			if (out_sizes) out_sizes[i] = checkpointer.flushed_sizes[i];
 		}
+	});
+}
+
+extern "C" int adach_db_reserve_staging(adach_db *h, uint64_t bytes) {
+	return Guard([&]() {
+		// page-locking the upload buffer is the one slow step of a first compaction round (hipHostMalloc: ~20 ms
+		// per 100 MB): an engine sizes it once, here, instead of inside the first policy step
+		std::lock_guard<std::mutex> pg(h->db->pool.lock);
+		h->db->pool.PinnedStaging(bytes);
+		h->db->pool.Staging(bytes);
 	});
 }
 

@@ -296,7 +296,8 @@ public:
 private:
 	friend class ColumnSegmentCatalog;
 	bool NeedsCompaction() const;
-	void FinishCompaction(bool packed, uint8_t width, uint64_t mn, uint64_t mx, int rule, uint64_t word_off);
+	void FinishCompaction(bool packed, uint8_t width, uint64_t mn, uint64_t mx, int rule, uint64_t word_off,
+	                      std::vector<std::vector<uint8_t>> *graveyard = nullptr);
 
 	idx_t num_elements = 0;
 	idx_t segment_size;

@@ -17,6 +17,7 @@ HOST_SIGNATURES = {
     "adach_db_create_cached": (_vp, [_int, _int, _int, _int, _u64, _u64]),
     "adach_db_cache_stats": (None, [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
     "adach_full_scan": (_int, [C.POINTER(_vp), _u64, _u64, C.POINTER(_u64), C.POINTER(C.c_double), C.POINTER(_u64)]),
+    "adach_db_reserve_staging": (_int, [_vp, _u64]),
     "adach_db_data_size": (_i64, [_vp]),
     "adach_db_arena_used_bytes": (_u64, [_vp]),
     "adach_compress_column": (_int, [_vp, _int, _int, _u64, _vp, _vp, _u64, C.POINTER(_vp), _u64, C.POINTER(_u64),
@@ -135,6 +136,9 @@ class Database:
             segs.append(s)
             self.segments.append(s)
         return segs, [sizes[i] for i in range(nseg.value)], score.value
+
+    def reserve_staging(self, nbytes):
+        _ok(hlib().adach_db_reserve_staging(self._h, nbytes), "reserve_staging")
 
     def cache_stats(self):
         h, m, b = _u64(), _u64(), _u64()

@@ -41,6 +41,9 @@ void adach_db_cache_stats(adach_db *db, uint64_t *hits, uint64_t *misses, uint64
  * ColumnSegment::Scan call), timed on the host; checksum = wrapping sum of every scanned row. */
 int adach_full_scan(adach_segment **segs, uint64_t nseg, uint64_t vector_size, uint64_t *checksum, double *seconds,
                     uint64_t *rows);
+/* Pre-size the page-locked upload buffer and its device twin (both otherwise grow on demand inside the first
+ * batched Compact: page-locking ~100 MB costs ~20 ms once). */
+int adach_db_reserve_staging(adach_db *db, uint64_t bytes);
 void adach_db_destroy(adach_db *db);
 int64_t adach_db_data_size(adach_db *db);          /* BufferManager::GetDataSize analogue */
 uint64_t adach_db_arena_used_bytes(adach_db *db);  /* HBM actually held by packed segments */
