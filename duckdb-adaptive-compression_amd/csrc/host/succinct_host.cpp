@@ -908,6 +908,25 @@ extern "C" void adach_db_cache_stats(adach_db *h, uint64_t *hits, uint64_t *miss
 
 // Full scan of a list of segments in the engine's call pattern — ColumnSegment::Scan on vector_size-row vectors
 // (ColumnData::ScanVector, column_data.cpp:92-139) — timed on the host; checksum = wrapping sum of all rows.
+template <typename T>
+static uint64_t SumTyped(const uint8_t *p, idx_t n) {
+	uint64_t acc = 0;
+	for (idx_t k = 0; k < n; k++) { // unaligned-safe, vectorises
+		T x;
+		std::memcpy(&x, p + k * sizeof(T), sizeof(T));
+		acc += x;
+	}
+	return acc;
+}
+static uint64_t SumVector(const uint8_t *p, idx_t n, idx_t type_size) {
+	switch (type_size) {
+	case 1: return SumTyped<uint8_t>(p, n);
+	case 2: return SumTyped<uint16_t>(p, n);
+	case 4: return SumTyped<uint32_t>(p, n);
+	default: return SumTyped<uint64_t>(p, n);
+	}
+}
+
 extern "C" int adach_full_scan(adach_segment **segs, uint64_t nseg, uint64_t vector_size, uint64_t *checksum,
                                double *seconds, uint64_t *rows_out) {
 	return Guard([&]() {
@@ -923,12 +942,7 @@ extern "C" int adach_full_scan(adach_segment **segs, uint64_t nseg, uint64_t vec
 				Vector v;
 				v.data = vec.data();
 				s.Scan(st, c, v, 0, true);
-				const idx_t ts = s.type_size;
-				for (idx_t k = 0; k < c; k++) { // the consumer touches every value
-					uint64_t x = 0;
-					std::memcpy(&x, vec.data() + k * ts, ts);
-					sum += x;
-				}
+				sum += SumVector(vec.data(), c, s.type_size); // the consumer touches every value
 				rows += c;
 			}
 		}
