@@ -403,6 +403,27 @@ def main():
             "note": "includes clearing the bitmap (hipMemsetAsync) before the kernel",
         }
         del d_bm
+        # A6: point fetch (SuccinctFetchRow) — 16 M uniformly random (segment, row) look-ups in one launch
+        nf = 1 << 24
+        frng = np.random.default_rng(99)
+        glob = frng.integers(0, args.rows, size=nf, dtype=np.int64)
+        starts = np.concatenate([[0], np.cumsum(counts.astype(np.int64))])
+        fseg = (np.searchsorted(starts, glob, side="right") - 1).astype(np.uint32)
+        frow = (glob - starts[fseg]).astype(np.uint32)
+        d_fseg = torch.from_numpy(fseg.view(np.int32)).to(col.d_vals.device)
+        d_frow = torch.from_numpy(frow.view(np.int32)).to(col.d_vals.device)
+        d_fout = torch.empty(nf, dtype=torch.int64, device=col.d_vals.device)
+        torch.cuda.synchronize()
+        fetch = lambda: col.layout.fetch_rows(col.d_words, d_fseg, d_frow, nf, d_fout)
+        fetch()
+        ctx.sync()
+        if not torch.equal(d_fout.cpu(), torch.from_numpy(vals[glob].view(np.int64))):
+            raise RuntimeError("parity failure: point fetch")
+        ms_f = time_launches(ctx, fetch, 10)
+        result["point_fetch"] = {"kernel": "k_fetch<u64>", "lookups": nf, "ms": ms_f,
+                                 "lookups_per_s": nf / (ms_f * 1e-3),
+                                 "note": "uniformly random rows of the C2 column, ids and results resident in HBM"}
+        del d_fseg, d_frow, d_fout
         # measured device copy rate, for "fraction of achievable" next to "fraction of spec peak"
         src = col.d_vals
         dst = torch.empty_like(src)
