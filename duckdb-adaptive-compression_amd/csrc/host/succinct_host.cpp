@@ -61,34 +61,67 @@ const uint8_t *SegmentPool::CacheLookup(const void *key) {
 	return it->second.data;
 }
 
+void SegmentPool::CacheReserve() {
+	if (cache_slab || cache_capacity < kCacheSlotBytes) return;
+	const size_t nslots = cache_capacity / kCacheSlotBytes;
+	void *p = nullptr;
+	if (adac_host_alloc_pinned(ctx, nslots * kCacheSlotBytes, &p) != ADAC_OK) return; // entries fall back to own blocks
+	cache_slab = static_cast<uint8_t *>(p);
+	cache_free_slots.reserve(nslots);
+	for (size_t i = nslots; i-- > 0;) cache_free_slots.push_back((int32_t)i);
+}
+
+static void CacheRelease(SegmentPool &pool, SegmentPool::CacheEntry &e) {
+	if (e.slot >= 0) {
+		pool.cache_free_slots.push_back(e.slot);
+	} else {
+		adac_host_free_pinned(pool.ctx, e.data);
+	}
+	pool.cache_used -= e.slot >= 0 ? SegmentPool::kCacheSlotBytes : e.bytes;
+}
+
 uint8_t *SegmentPool::CacheInsert(const void *key, size_t bytes) {
 	if (bytes > cache_capacity) return nullptr;
-	while (cache_used + bytes > cache_capacity && !cache.empty()) {
-		auto victim = cache.begin();
+	CacheReserve();
+	const bool slotted = cache_slab && bytes <= kCacheSlotBytes;
+	const size_t charge = slotted ? kCacheSlotBytes : bytes;
+	while ((cache_used + charge > cache_capacity || (slotted && cache_free_slots.empty())) && !cache.empty()) {
+		auto victim = cache.begin(); // least recently used
 		for (auto it = cache.begin(); it != cache.end(); ++it) {
 			if (it->second.stamp < victim->second.stamp) victim = it;
 		}
-		adac_host_free_pinned(ctx, victim->second.data);
-		cache_used -= victim->second.bytes;
+		CacheRelease(*this, victim->second);
 		cache.erase(victim);
 	}
-	void *p = nullptr;
-	if (adac_host_alloc_pinned(ctx, bytes, &p) != ADAC_OK) return nullptr;
-	cache[key] = CacheEntry {static_cast<uint8_t *>(p), bytes, ++cache_clock};
-	cache_used += bytes;
-	return static_cast<uint8_t *>(p);
+	CacheEntry e;
+	e.bytes = bytes;
+	e.stamp = ++cache_clock;
+	if (slotted && !cache_free_slots.empty()) {
+		e.slot = cache_free_slots.back();
+		cache_free_slots.pop_back();
+		e.data = cache_slab + (size_t)e.slot * kCacheSlotBytes;
+	} else {
+		void *p = nullptr;
+		if (adac_host_alloc_pinned(ctx, bytes, &p) != ADAC_OK) return nullptr;
+		e.data = static_cast<uint8_t *>(p);
+	}
+	cache[key] = e;
+	cache_used += e.slot >= 0 ? kCacheSlotBytes : bytes;
+	return e.data;
 }
 
 void SegmentPool::CacheDrop(const void *key) {
 	auto it = cache.find(key);
 	if (it == cache.end()) return;
-	adac_host_free_pinned(ctx, it->second.data);
-	cache_used -= it->second.bytes;
+	CacheRelease(*this, it->second);
 	cache.erase(it);
 }
 
 SegmentPool::~SegmentPool() {
-	for (auto &e : cache) adac_host_free_pinned(ctx, e.second.data);
+	for (auto &e : cache) {
+		if (e.second.slot < 0) adac_host_free_pinned(ctx, e.second.data);
+	}
+	if (cache_slab) adac_host_free_pinned(ctx, cache_slab);
 	if (h_pinned) adac_host_free_pinned(ctx, h_pinned);
 	if (d_staging) adac_dev_free(ctx, d_staging);
 	if (d_staging2) adac_dev_free(ctx, d_staging2);
@@ -326,6 +359,7 @@ CompressionFunction UncompressedFun::GetFunction(PhysicalType data_type) {
 DatabaseInstance::DatabaseInstance(int device, const DBConfig &config_p, size_t arena_bytes)
     : config(config_p), pool(device, arena_bytes), catalog(*this) {
 	pool.cache_capacity = config.decoded_cache_bytes;
+	pool.CacheReserve();
 }
 
 const CompressionFunction *DatabaseInstance::GetCompressionFunction(CompressionType type, PhysicalType data_type) {

@@ -168,9 +168,16 @@ public:
 		uint8_t *data = nullptr;
 		size_t bytes = 0;
 		uint64_t stamp = 0;
+		int32_t slot = -1; // >= 0: a slot of the slab; -1: its own page-locked allocation (oversized segment)
 	};
 	uint64_t cache_capacity = 0, cache_used = 0, cache_clock = 0, cache_hits = 0, cache_misses = 0;
 	std::unordered_map<const void *, CacheEntry> cache;
+	// The cache's page-locked memory is ONE slab cut into block-sized slots: page-locking costs ~50 us per 256 KiB
+	// block, which made every cold segment pay more for its buffer than for its decode and copy.
+	static constexpr size_t kCacheSlotBytes = 262144;
+	uint8_t *cache_slab = nullptr;
+	std::vector<int32_t> cache_free_slots;
+	void CacheReserve(); // allocates the slab (idempotent); called when a cache capacity is configured
 	const uint8_t *CacheLookup(const void *key);
 	uint8_t *CacheInsert(const void *key, size_t bytes); // evicts least-recently-used entries; nullptr if too big
 	void CacheDrop(const void *key);
