@@ -489,7 +489,11 @@ void ColumnSegment::ScanRows(idx_t start_row, idx_t scan_count, data_ptr_t targe
 		void *d_out = db.pool.Staging(scan_count * type_size);
 		Check(adac_unpack_range(LayoutOf(device_layout), db.pool.d_arena, layout_index, start_row, scan_count, d_out, 0),
 		      "adac_unpack_range");
-		Check(adac_memcpy_d2h(db.pool.ctx, target, d_out, scan_count * type_size), "adac_memcpy_d2h");
+		// the engine's result vector is pageable memory: copy down into the page-locked staging block (a direct
+		// DMA) and move the few KiB from there, instead of letting the runtime stage the copy itself
+		uint8_t *bounce = db.pool.PinnedStaging(scan_count * type_size);
+		Check(adac_memcpy_d2h(db.pool.ctx, bounce, d_out, scan_count * type_size), "adac_memcpy_d2h");
+		std::memcpy(target, bounce, scan_count * type_size);
 	} else {
 		// unpacked slots / uncompressed block: the bytes ARE the values (no min add: SURVEY.md §8a (iii))
 		std::memcpy(target, raw.data() + start_row * type_size, scan_count * type_size);
@@ -745,7 +749,9 @@ void ColumnSegment::Uncompact() {
 			void *d_out = db.pool.Staging(count * type_size);
 			Check(adac_unpack_range(LayoutOf(device_layout), db.pool.d_arena, layout_index, 0, count, d_out, 0),
 			      "adac_unpack_range");
-			Check(adac_memcpy_d2h(db.pool.ctx, raw.data(), d_out, count * type_size), "adac_memcpy_d2h");
+			uint8_t *bounce = db.pool.PinnedStaging(count * type_size);
+			Check(adac_memcpy_d2h(db.pool.ctx, bounce, d_out, count * type_size), "adac_memcpy_d2h");
+			std::memcpy(raw.data(), bounce, count * type_size);
 		}
 		db.pool.Free(word_off, arena_words);
 		db.pool.CacheDrop(this);
