@@ -209,7 +209,7 @@ def q6_packed(adac, n=59_986_052):
         for _ in range(reps):
             q6()
         by_group[group] = ctx.timer_stop() / reps
-    adac.set_tuning("scan_tiles_per_wg", 16)
+    adac.set_tuning("scan_tiles_per_wg", 0)
     ctx.timer_start()
     for _ in range(reps):
         q6()

@@ -49,6 +49,13 @@ struct adac_layout {
 	adac_segment_desc *d_descs = nullptr;
 	TileRef *d_tiles = nullptr;
 	uint64_t *d_minmax = nullptr;
+	// fused-scan work items (see ScanGroup): built lazily for the current scan_tiles_per_wg, re-expanded when
+	// the descriptors changed
+	adac::ScanGroupRef *d_group_refs = nullptr;
+	adac::ScanGroup *d_groups = nullptr;
+	uint64_t ngroups = 0;
+	int groups_tiles = 0;
+	bool groups_dirty = true;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -175,7 +182,7 @@ extern "C" int adac_set_tuning(const char *name, int value) {
 	if (n == "persistent_unpack") adac::g_tuning.persistent_unpack = value;
 	else if (n == "scan_probe") adac::g_tuning.scan_probe = value;
 	else if (n == "templated_scan") adac::g_tuning.templated_scan = value;
-	else if (n == "scan_tiles_per_wg" && value > 0) adac::g_tuning.scan_tiles_per_wg = value;
+	else if (n == "scan_tiles_per_wg" && value >= 0) adac::g_tuning.scan_tiles_per_wg = value; // 0 = by type
 	else if (n == "blocks_per_cu" && value > 0) adac::g_tuning.blocks_per_cu = value;
 	else if (n == "num_cus" && value > 0) adac::g_tuning.num_cus = value;
 	else return 1;
@@ -382,6 +389,8 @@ extern "C" void adac_layout_destroy(adac_layout *l) {
 	if (l->d_descs) (void)hipFree(l->d_descs);
 	if (l->d_tiles) (void)hipFree(l->d_tiles);
 	if (l->d_minmax) (void)hipFree(l->d_minmax);
+	if (l->d_group_refs) (void)hipFree(l->d_group_refs);
+	if (l->d_groups) (void)hipFree(l->d_groups);
 	delete l;
 }
 
@@ -407,6 +416,7 @@ extern "C" adac_status adac_layout_set_descs(adac_layout *l, const adac_segment_
 		                        l->ctx->stream));
 		ADAC_HIP(hipStreamSynchronize(l->ctx->stream));
 	}
+	l->groups_dirty = true;
 	return ADAC_OK;
 }
 
@@ -467,6 +477,7 @@ extern "C" adac_status adac_plan(adac_layout *l, int rule, int pad_to_byte) {
 	ADAC_HIP(hipSetDevice(l->ctx->device));
 	ADAC_HIP(adac::launch_plan(l->ctx->stream, l->type_size, rule, pad_to_byte ? 1 : 0, l->d_descs, l->d_minmax,
 	                           l->nseg));
+	l->groups_dirty = true;
 	return ADAC_OK;
 }
 
@@ -558,6 +569,52 @@ extern "C" adac_status adac_fetch_rows(adac_layout *l, const uint64_t *d_words, 
 	return ADAC_OK;
 }
 
+// The scans' work items for the current grouping knob; the expansion kernel runs on the codec stream, so it is
+// ordered after the plan / descriptor upload that made it necessary.
+static adac_status ensure_scan_groups(adac_layout *l) {
+	// A segment's tiles are dealt EVENLY to ceil(tiles / target) workgroups.  Default target: ~24 K rows (12 tiles
+	// of u64, 6 of u32), so a 16-tile DuckDB segment becomes two groups of 8 tiles.  Measured (tools/ab_tuning.py,
+	// 400 M rows): a whole 32 767-row segment per workgroup puts the workgroups' packed streams and bitmap regions
+	// at the same power-of-two stride (32 KiB / 4 KiB) and costs 6-25 %; 16-24 K rows is the best of 4 .. 32 tiles
+	const uint32_t tile = adac::tile_values(l->type_size);
+	int per = adac::g_tuning.scan_tiles_per_wg;
+	if (per < 1) per = (int)(24576u / tile) < 1 ? 1 : (int)(24576u / tile);
+	if (l->groups_tiles != per) {
+		std::vector<adac::ScanGroupRef> refs;
+		for (uint64_t s = 0; s < l->nseg; s++) {
+			const uint64_t ntiles = ((uint64_t)l->counts[s] + tile - 1) / tile;
+			if (ntiles == 0) continue;
+			const uint64_t ngroups = (ntiles + (uint64_t)per - 1) / (uint64_t)per;
+			const uint64_t rows_per_group = ((ntiles + ngroups - 1) / ngroups) * tile;
+			for (uint64_t first = 0; first < l->counts[s]; first += rows_per_group) {
+				const uint64_t left = l->counts[s] - first;
+				refs.push_back(adac::ScanGroupRef {(uint32_t)s, (uint32_t)first,
+				                                   (uint32_t)(left < rows_per_group ? left : rows_per_group), 0u});
+			}
+		}
+		if (refs.size() >= 0x7fffffffull) return ADAC_ERR_INVALID_ARGUMENT;
+		if (l->d_group_refs) (void)hipFree(l->d_group_refs);
+		if (l->d_groups) (void)hipFree(l->d_groups);
+		l->d_group_refs = nullptr;
+		l->d_groups = nullptr;
+		l->ngroups = refs.size();
+		ADAC_HIP(hipMalloc((void **)&l->d_group_refs, (refs.size() ? refs.size() : 1) * sizeof(adac::ScanGroupRef)));
+		ADAC_HIP(hipMalloc((void **)&l->d_groups, (refs.size() ? refs.size() : 1) * sizeof(adac::ScanGroup)));
+		if (!refs.empty()) {
+			ADAC_HIP(hipMemcpyAsync(l->d_group_refs, refs.data(), refs.size() * sizeof(adac::ScanGroupRef),
+			                        hipMemcpyHostToDevice, l->ctx->stream));
+			ADAC_HIP(hipStreamSynchronize(l->ctx->stream)); // refs is stack-local
+		}
+		l->groups_tiles = per;
+		l->groups_dirty = true;
+	}
+	if (l->groups_dirty) {
+		ADAC_HIP(adac::launch_expand_groups(l->ctx->stream, l->d_descs, l->d_group_refs, l->ngroups, l->d_groups));
+		l->groups_dirty = false;
+	}
+	return ADAC_OK;
+}
+
 extern "C" adac_status adac_scan_sum_valid(adac_layout *l, const uint64_t *d_words, const uint64_t *d_validity,
                                            uint64_t *d_sums);
 extern "C" adac_status adac_scan_sum(adac_layout *l, const uint64_t *d_words, uint64_t *d_sums) {
@@ -571,8 +628,10 @@ extern "C" adac_status adac_scan_sum_valid(adac_layout *l, const uint64_t *d_wor
 	ADAC_HIP(hipSetDevice(l->ctx->device));
 	if (l->nseg) ADAC_HIP(hipMemsetAsync(d_sums, 0, l->nseg * sizeof(uint64_t), l->ctx->stream));
 	const uint64_t sbit = l->is_signed ? (1ull << (8 * l->type_size - 1)) : 0ull;
-	ADAC_HIP(adac::launch_scan_sum(l->ctx->stream, l->type_size, l->d_descs, l->d_tiles, l->ntiles, d_words, d_validity,
-	                               sbit, d_sums));
+	adac_status gst = ensure_scan_groups(l);
+	if (gst != ADAC_OK) return gst;
+	ADAC_HIP(adac::launch_scan_sum(l->ctx->stream, l->type_size, l->d_groups, l->ngroups, d_words, d_validity, sbit,
+	                               d_sums));
 	return ADAC_OK;
 }
 
@@ -600,8 +659,10 @@ static adac_status scan_range(adac_layout *l, const uint64_t *d_words, const uin
 	const uint64_t sbit = l->is_signed ? (1ull << (bits - 1)) : 0ull;
 	const uint64_t blo = (lo & umask) ^ sbit, bhi = (hi & umask) ^ sbit;
 	if (bhi < blo) return ADAC_OK; // empty range: all counts (and bits) stay zero
-	ADAC_HIP(adac::launch_scan_count_range(l->ctx->stream, l->type_size, l->d_descs, l->d_tiles, l->ntiles, d_words,
-	                                       d_validity, blo, bhi - blo, sbit, d_counts, want_bitmap ? d_bitmap : nullptr));
+	adac_status gst = ensure_scan_groups(l);
+	if (gst != ADAC_OK) return gst;
+	ADAC_HIP(adac::launch_scan_count_range(l->ctx->stream, l->type_size, l->d_groups, l->ngroups, d_words, d_validity,
+	                                       blo, bhi - blo, sbit, d_counts, want_bitmap ? d_bitmap : nullptr));
 	return ADAC_OK;
 }
 

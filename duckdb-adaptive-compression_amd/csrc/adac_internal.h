@@ -19,6 +19,25 @@ struct TileRef {
 	uint32_t first;
 };
 
+// Work item of the fused scans: `ntiles` consecutive tiles of ONE segment starting at row `first` (static per
+// layout and grouping), and its expansion with the segment's current descriptor (rebuilt whenever descriptors
+// change): a scan workgroup then needs ONE 64-byte load before its first data load instead of the dependent
+// chain tile entry -> descriptor.
+struct ScanGroupRef {
+	uint32_t seg;
+	uint32_t first;
+	uint32_t rows; // a segment's tiles are dealt evenly to its groups, so group sizes differ between segments
+	uint32_t pad;
+};
+struct alignas(64) ScanGroup {
+	adac_segment_desc d;
+	uint32_t seg;
+	uint32_t first;
+	uint32_t n; // rows
+	uint32_t pad[5];
+};
+static_assert(sizeof(ScanGroup) == 64, "one cache-line record per scan group");
+
 // Single-segment range decode (scan_vector / scan_partial): tiles are implicit.
 struct RangeArgs {
 	uint32_t seg;
@@ -33,7 +52,7 @@ struct Tuning {
 	int persistent_unpack = 0;  // measured 5-15 % slower than one tile per workgroup (profiles/r01_ab_*.json)
 	int scan_probe = 0;         // diagnostic: fused-scan loop + loads only (no field walk)
 	int templated_scan = 1;     // width-templated register path of the fused scans for 4 <= w <= 32
-	int scan_tiles_per_wg = 16; // tile-table entries per fused-scan workgroup
+	int scan_tiles_per_wg = 0; // tiles per fused-scan workgroup; 0 = ~24 K rows (12 tiles of u64, 6 of u32, ...)
 	int num_cus = 256;      // MI355X: 8 XCDs x 32 CUs
 	int blocks_per_cu = 8;  // 256-thread workgroups resident per CU (2048 threads, <= 16.5 KiB LDS each)
 };
@@ -65,12 +84,13 @@ hipError_t launch_analyze_packed(hipStream_t s, uint32_t type_size, bool sign_ex
 hipError_t launch_repack(hipStream_t s, uint32_t type_size, uint64_t null_bits, const adac_segment_desc *d_src_descs,
                          const adac_segment_desc *d_dst_descs, const TileRef *d_tiles, uint64_t ntiles,
                          const uint64_t *d_src_words, const uint64_t *d_validity, uint64_t *d_dst_words);
-hipError_t launch_scan_sum(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs, const TileRef *d_tiles,
-                           uint64_t ntiles, const uint64_t *d_words, const uint64_t *d_validity, uint64_t sbit, uint64_t *d_sums);
-hipError_t launch_scan_count_range(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs,
-                                   const TileRef *d_tiles, uint64_t ntiles, const uint64_t *d_words,
-                                   const uint64_t *d_validity, uint64_t blo, uint64_t bspan, uint64_t sbit,
-                                   uint64_t *d_counts, uint64_t *d_bitmap);
+hipError_t launch_expand_groups(hipStream_t s, const adac_segment_desc *d_descs, const ScanGroupRef *d_refs,
+                                uint64_t ngroups, ScanGroup *d_groups);
+hipError_t launch_scan_sum(hipStream_t s, uint32_t type_size, const ScanGroup *d_groups, uint64_t ngroups,
+                           const uint64_t *d_words, const uint64_t *d_validity, uint64_t sbit, uint64_t *d_sums);
+hipError_t launch_scan_count_range(hipStream_t s, uint32_t type_size, const ScanGroup *d_groups, uint64_t ngroups,
+                                   const uint64_t *d_words, const uint64_t *d_validity, uint64_t blo, uint64_t bspan,
+                                   uint64_t sbit, uint64_t *d_counts, uint64_t *d_bitmap);
 
 // DuckDB BITPACKING segments (adac_bitpacking.inl).  Host view of one metadata group; must match BpGroup.
 struct BpGroupHost {

@@ -517,18 +517,18 @@ __device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint
 		fr = field_range<U>(pred, d, mask, linear);
 		if (!fr.any) return; // zonemap-style skip: no row of this segment can satisfy the predicate
 	}
-	// lane -> chunk map.  Aggregates: the workgroup strides over the run together.  Selection: each wave takes a
-	// contiguous quarter and whole waves stay in the loop (Lw is the wave's first chunk; lanes past `lend`
-	// carry no rows)
-	uint32_t L, Lw, lend;
+	// lane -> chunk map.  Aggregates: the workgroup strides over the run together.  Selection: the run is cut into
+	// blocks of kSelBlock x 64 chunks dealt round-robin to the four waves; a wave walks its block in kSelBlock
+	// iterations (adjacent rows, one bitmap flush per block) and whole waves stay in the loop — Lw is the wave's
+	// first chunk of the iteration, lanes past the run carry no rows
+	constexpr uint32_t kBlockChunks = kSelBlock * 64u;
+	uint32_t L, Lw;
+	const uint32_t lend = c1;
 	if (OP == 3) {
-		const uint32_t per_wave = ((c1 - c0 + kWorkgroup - 1) / kWorkgroup) * 64u;
-		Lw = c0 + (threadIdx.x >> 6) * per_wave;
-		lend = Lw + per_wave < c1 ? Lw + per_wave : c1;
+		Lw = c0 + (threadIdx.x >> 6) * kBlockChunks;
 		L = Lw + (threadIdx.x & 63u);
 	} else {
 		L = Lw = c0 + threadIdx.x;
-		lend = c1;
 	}
 	if (Lw >= lend) return;
 	// selection bookkeeping (wave-uniform)
@@ -541,8 +541,11 @@ __device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint
 	const uint32_t Lc = L < clast ? L : clast;
 	uint4 q = seg16[Lc];
 	uint32_t e = reinterpret_cast<const uint32_t *>(seg16 + (Lc < clast ? Lc + 1 : clast))[0];
-	for (; Lw < lend; L += STRIDE, Lw += STRIDE) {
-		const uint32_t Lp = L + STRIDE < clast ? L + STRIDE : clast;
+	uint32_t adv = STRIDE;
+	for (; Lw < lend; L += adv, Lw += adv) {
+		// selection: 64 chunks on inside a block, then on to this wave's next block
+		if (OP == 3) adv = blk_iter == kSelBlock - 1u ? (uint32_t)(kWorkgroup / 64) * kBlockChunks - (kSelBlock - 1u) * 64u : 64u;
+		const uint32_t Lp = L + adv < clast ? L + adv : clast;
 		const uint4 qn = seg16[Lp];
 		const uint32_t en = reinterpret_cast<const uint32_t *>(seg16 + (Lp < clast ? Lp + 1 : clast))[0];
 		const uint32_t i0 = (128u * L + (W - 1)) / W; // first row starting in this chunk
@@ -564,8 +567,7 @@ __device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint
 		if (PRED) {
 			// bit j of `hits` = row i0 + j satisfies the predicate: built top-down so that each field costs
 			// extract, subtract, compare and one add-with-carry (hits = 2 * hits + hit)
-			uint32_t have = starting < lim ? starting : lim;
-			if (OP == 3 && L >= lend) have = 0u; // the next wave's chunk
+			const uint32_t have = starting < lim ? starting : lim; // 0 for lanes past the run
 			uint32_t hits = 0;
 #pragma unroll
 			for (int j = MAXV - 1; j >= 0; j--) {
@@ -636,14 +638,30 @@ __device__ __forceinline__ void scan_run_dispatch(uint32_t w, const uint4 *__res
 	}
 }
 
-// OP 0: SUM, 1: COUNT(lo <= v <= hi), 2: load-only probe, 3: COUNT + selection bitmap; V: validity mask given
+// Expansion of the scans' work items: one thread per group copies its segment's CURRENT descriptor next to the
+// group's row range, so the scan kernel reads one 64-byte record (a single hop) before it can issue data loads.
+__global__ void k_expand_groups(const adac_segment_desc *__restrict__ descs, const ScanGroupRef *__restrict__ refs,
+                                uint64_t ngroups, ScanGroup *__restrict__ groups) {
+	const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= ngroups) return;
+	const ScanGroupRef r = refs[g];
+	ScanGroup out;
+	out.d = descs[r.seg];
+	out.seg = r.seg;
+	out.first = r.first;
+	out.n = r.rows;
+#pragma unroll
+	for (int i = 0; i < 5; i++) out.pad[i] = 0;
+	groups[g] = out;
+}
+
+// OP 0: SUM, 1: COUNT(lo <= v <= hi), 2: load-only probe, 3: COUNT + selection bitmap; V: validity mask given.
+// One workgroup per ScanGroup: up to scan_tiles_per_wg consecutive tiles of ONE segment.
 template <typename U, int OP, bool V>
-__global__ __launch_bounds__(kWorkgroup, 6) void k_scan_agg(const adac_segment_desc *__restrict__ descs,
-                                                         const TileRef *__restrict__ tiles, uint32_t ntiles,
-                                                         uint32_t group, int templated,
-                                                         const uint64_t *__restrict__ words, RangePred pred,
-                                                         const uint64_t *__restrict__ validity,
-                                                         uint64_t *__restrict__ result, uint32_t *__restrict__ bitmap32) {
+__global__ __launch_bounds__(kWorkgroup, 6) void k_scan_agg(const ScanGroup *__restrict__ groups, int templated,
+                                                            const uint64_t *__restrict__ words, RangePred pred,
+                                                            const uint64_t *__restrict__ validity,
+                                                            uint64_t *__restrict__ result, uint32_t *__restrict__ bitmap32) {
 	constexpr uint32_t TILE = kTileBytes / sizeof(U);
 	__shared__ uint4 lds[kTileBytes / 16 + 2];
 	__shared__ uint32_t sel_words[OP == 3 ? (kWorkgroup / 64) * kSelWordsPerWave : 1];
@@ -654,90 +672,70 @@ __global__ __launch_bounds__(kWorkgroup, 6) void k_scan_agg(const adac_segment_d
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	}
 	const uint32_t *lds32 = reinterpret_cast<const uint32_t *>(lds);
-	uint32_t t = blockIdx.x * group;
-	const uint32_t hi = t + group < ntiles ? t + group : ntiles;
+	const ScanGroup g = groups[blockIdx.x];
+	const adac_segment_desc &d = g.d;
 	uint64_t acc = 0;
-	uint32_t seg = tiles[t].seg;
-	auto flush = [&](uint32_t to_seg) {
-		const uint64_t tot = wave_sum(acc);
-		if ((threadIdx.x & 63) == 0 && tot != 0) { // wrapping sums commute: one atomic per wave and run
-			atomicAdd(reinterpret_cast<unsigned long long *>(result + to_seg), (unsigned long long)tot);
-		}
-		acc = 0;
-	};
-	while (t < hi) {
-		const TileRef r = tiles[t];
-		if (r.seg != seg) { // wave-uniform
-			flush(seg);
-			seg = r.seg;
-		}
-		const adac_segment_desc d = descs[r.seg];
-		const uint32_t w = d.width;
-		const SegKind kind = seg_kind<U>(d, pred.sbit);
-		// the register path works on fields: linear segments, and raw ones whose field IS the value it needs
-		// (unsigned T; for the predicates also 32-bit signed T, whose order is a shift of the field's)
-		const bool by_field = kind == SEG_LINEAR ||
-		                      (kind == SEG_RAW && (pred.sbit == 0 || ((OP == 1 || OP == 3) && sizeof(U) == 4)));
-		if (templated && w >= 4 && w <= 32 && (uint64_t)d.count * w < (1ull << 31) && by_field) {
-			// width-templated register path: the whole run of this segment's tiles in this group, no LDS
-			// tiles of one segment are consecutive table entries, so the run length is arithmetic (walking the
-			// table entry by entry costs one dependent scalar load per tile: measured 3.0 -> TB/s-bound)
-			const uint32_t left = d.count - r.first;
-			const uint32_t tiles_left = (left + TILE - 1) / TILE;
-			const uint32_t run = tiles_left < hi - t ? tiles_left : hi - t;
-			const uint32_t n = left < run * TILE ? left : run * TILE;
-			const uint4 *seg16 = reinterpret_cast<const uint4 *>(words + d.word_off);
-			scan_run_dispatch<U, OP, V>(w, seg16, r.first, r.first + n, d, pred, kind == SEG_LINEAR, validity, sel_out,
-			                            acc);
-			t += run;
-			continue;
-		}
+	const uint32_t w = d.width;
+	const SegKind kind = seg_kind<U>(d, pred.sbit);
+	// the register path works on fields: linear segments, and raw ones whose field IS the value it needs
+	// (unsigned T; for the predicates also 32-bit signed T, whose order is a shift of the field's)
+	const bool by_field = kind == SEG_LINEAR ||
+	                      (kind == SEG_RAW && (pred.sbit == 0 || ((OP == 1 || OP == 3) && sizeof(U) == 4)));
+	if (templated && w >= 4 && w <= 32 && (uint64_t)d.count * w < (1ull << 31) && by_field) {
+		// width-templated register path over the whole group, no LDS
+		const uint4 *seg16 = reinterpret_cast<const uint4 *>(words + d.word_off);
+		scan_run_dispatch<U, OP, V>(w, seg16, g.first, g.first + g.n, d, pred, kind == SEG_LINEAR, validity, sel_out,
+		                            acc);
+	} else {
 		uint32_t fit = (8u * kTileBytes) / (TILE * w); // whole tiles of this width per LDS image
 		fit = fit < 1u ? 1u : fit;
-		const uint32_t left = d.count - r.first;
-		const uint32_t tiles_left = (left + TILE - 1) / TILE;
-		uint32_t run = tiles_left < hi - t ? tiles_left : hi - t;
-		run = run < fit ? run : fit;
-		const uint32_t n = left < run * TILE ? left : run * TILE;
-		const uint32_t bit0 = stage_packed(words + d.word_off, r.first, n, w, lds);
-		__syncthreads();
-		const uint64_t elem0 = d.val_off + r.first;
-		auto sink = [&](int32_t base, const U *vals, bool full) {
-			constexpr int KK = 16 / (int)sizeof(U);
-			const uint32_t vbits = V ? validity_window(validity, elem0 + (uint32_t)(base < 0 ? 0 : base)) : 0xffffffffu;
-			if (OP == 3) { // decode_run walks with align 0: base >= 0, lanes ascending
-				uint32_t hits = 0;
+		for (uint32_t done = 0; done < g.n;) { // the group in stages of as many tiles as fit the image
+			const uint32_t first = g.first + done;
+			const uint32_t left = g.n - done;
+			const uint32_t n = left < fit * TILE ? left : fit * TILE;
+			const uint32_t bit0 = stage_packed(words + d.word_off, first, n, w, lds);
+			__syncthreads();
+			const uint64_t elem0 = d.val_off + first;
+			auto sink = [&](int32_t base, const U *vals, bool full) {
+				constexpr int KK = 16 / (int)sizeof(U);
+				const uint32_t vbits = V ? validity_window(validity, elem0 + (uint32_t)(base < 0 ? 0 : base)) : 0xffffffffu;
+				if (OP == 3) { // decode_run walks with align 0: base >= 0, lanes ascending
+					uint32_t hits = 0;
+#pragma unroll
+					for (int j = 0; j < KK; j++) {
+						hits |= (((((uint64_t)vals[j] ^ pred.sbit) - pred.blo) <= pred.bspan) ? 1u : 0u) << j;
+					}
+					const uint32_t rest = n - (uint32_t)base;
+					const uint32_t have = full || rest >= (uint32_t)KK ? (uint32_t)KK : rest;
+					hits &= vbits & ((1u << have) - 1u);
+					acc += (uint32_t)__popc(hits);
+					wave_emit_bits(sel_out, elem0 + (uint32_t)base, hits, have);
+					return;
+				}
 #pragma unroll
 				for (int j = 0; j < KK; j++) {
-					hits |= (((((uint64_t)vals[j] ^ pred.sbit) - pred.blo) <= pred.bspan) ? 1u : 0u) << j;
-				}
-				const uint32_t left = n - (uint32_t)base;
-				const uint32_t have = full || left >= (uint32_t)KK ? (uint32_t)KK : left;
-				hits &= vbits & ((1u << have) - 1u);
-				acc += (uint32_t)__popc(hits);
-				wave_emit_bits(sel_out, elem0 + (uint32_t)base, hits, have);
-				return;
-			}
-#pragma unroll
-			for (int j = 0; j < KK; j++) {
-				if ((full || (uint32_t)(base + j) < n) && ((vbits >> j) & 1u)) {
-					if (OP == 1) {
-						acc += (((uint64_t)vals[j] ^ pred.sbit) - pred.blo) <= pred.bspan ? 1ull : 0ull;
-					} else {
-						acc += ((uint64_t)vals[j] ^ pred.sbit) - pred.sbit; // widened by T's signedness
+					if ((full || (uint32_t)(base + j) < n) && ((vbits >> j) & 1u)) {
+						if (OP == 1) {
+							acc += (((uint64_t)vals[j] ^ pred.sbit) - pred.blo) <= pred.bspan ? 1ull : 0ull;
+						} else {
+							acc += ((uint64_t)vals[j] ^ pred.sbit) - pred.sbit; // widened by T's signedness
+						}
 					}
 				}
+			};
+			if (sizeof(U) == 8 && w > 32) {
+				decode_run<U, true>(lds32, bit0, w, effective_add(d), n, sink);
+			} else {
+				decode_run<U, false>(lds32, bit0, w, effective_add(d), n, sink);
 			}
-		};
-		if (sizeof(U) == 8 && w > 32) {
-			decode_run<U, true>(lds32, bit0, w, effective_add(d), n, sink);
-		} else {
-			decode_run<U, false>(lds32, bit0, w, effective_add(d), n, sink);
+			__syncthreads(); // the image is rewritten by the next stage
+			done += n;
 		}
-		__syncthreads(); // the image is rewritten by the next stage
-		t += run;
 	}
-	flush(seg);
+	const uint64_t tot = wave_sum(acc);
+	if ((threadIdx.x & 63) == 0 && tot != 0) { // wrapping sums commute: one atomic per wave and group
+		atomicAdd(reinterpret_cast<unsigned long long *>(result + g.seg), (unsigned long long)tot);
+	}
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1360,50 +1358,50 @@ hipError_t launch_fetch(hipStream_t s, uint32_t type_size, const adac_segment_de
 	});
 }
 
-hipError_t launch_scan_sum(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs, const TileRef *d_tiles,
-                           uint64_t ntiles, const uint64_t *d_words, const uint64_t *d_validity, uint64_t sbit,
-                           uint64_t *d_sums) {
-	if (ntiles == 0) return hipSuccess;
+hipError_t launch_expand_groups(hipStream_t s, const adac_segment_desc *d_descs, const ScanGroupRef *d_refs,
+                                uint64_t ngroups, ScanGroup *d_groups) {
+	if (ngroups == 0) return hipSuccess;
+	hipLaunchKernelGGL(k_expand_groups, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, s, d_descs, d_refs,
+	                   ngroups, d_groups);
+	return hipGetLastError();
+}
+
+hipError_t launch_scan_sum(hipStream_t s, uint32_t type_size, const ScanGroup *d_groups, uint64_t ngroups,
+                           const uint64_t *d_words, const uint64_t *d_validity, uint64_t sbit, uint64_t *d_sums) {
+	if (ngroups == 0) return hipSuccess;
 	const RangePred widen {0ull, 0ull, sbit}; // SUM only needs T's sign bit
 	return dispatch_size(type_size, [&](auto tag) {
 		using U = decltype(tag);
-		const uint32_t per = (uint32_t)g_tuning.scan_tiles_per_wg;
-		const dim3 grid((unsigned)((ntiles + per - 1) / per));
+		const dim3 grid((unsigned)ngroups);
+		const int tpl = g_tuning.templated_scan;
+		uint32_t *no_bitmap = nullptr;
 		if (g_tuning.scan_probe) { // diagnostic: the scan's loop and loads without the field walk (result meaningless)
-			hipLaunchKernelGGL((k_scan_agg<U, 2, false>), grid, dim3(kWorkgroup), 0, s, d_descs, d_tiles, (uint32_t)ntiles, per,
-			                   1, d_words, RangePred {}, static_cast<const uint64_t *>(nullptr), d_sums,
-			                   static_cast<uint32_t *>(nullptr));
-			return hipGetLastError();
-		}
-		if (d_validity) {
-			hipLaunchKernelGGL((k_scan_agg<U, 0, true>), grid, dim3(kWorkgroup), 0, s, d_descs, d_tiles, (uint32_t)ntiles,
-			                   per, g_tuning.templated_scan, d_words, widen, d_validity, d_sums,
-			                   static_cast<uint32_t *>(nullptr));
+			hipLaunchKernelGGL((k_scan_agg<U, 2, false>), grid, dim3(kWorkgroup), 0, s, d_groups, 1, d_words, RangePred {},
+			                   static_cast<const uint64_t *>(nullptr), d_sums, no_bitmap);
+		} else if (d_validity) {
+			hipLaunchKernelGGL((k_scan_agg<U, 0, true>), grid, dim3(kWorkgroup), 0, s, d_groups, tpl, d_words, widen,
+			                   d_validity, d_sums, no_bitmap);
 		} else {
-			hipLaunchKernelGGL((k_scan_agg<U, 0, false>), grid, dim3(kWorkgroup), 0, s, d_descs, d_tiles,
-			                   (uint32_t)ntiles, per, g_tuning.templated_scan, d_words, widen, d_validity, d_sums,
-			                   static_cast<uint32_t *>(nullptr));
+			hipLaunchKernelGGL((k_scan_agg<U, 0, false>), grid, dim3(kWorkgroup), 0, s, d_groups, tpl, d_words, widen,
+			                   d_validity, d_sums, no_bitmap);
 		}
 		return hipGetLastError();
 	});
 }
 
-hipError_t launch_scan_count_range(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs,
-                                   const TileRef *d_tiles, uint64_t ntiles, const uint64_t *d_words,
-                                   const uint64_t *d_validity, uint64_t blo, uint64_t bspan, uint64_t sbit,
-                                   uint64_t *d_counts, uint64_t *d_bitmap) {
-	if (ntiles == 0) return hipSuccess;
+hipError_t launch_scan_count_range(hipStream_t s, uint32_t type_size, const ScanGroup *d_groups, uint64_t ngroups,
+                                   const uint64_t *d_words, const uint64_t *d_validity, uint64_t blo, uint64_t bspan,
+                                   uint64_t sbit, uint64_t *d_counts, uint64_t *d_bitmap) {
+	if (ngroups == 0) return hipSuccess;
 	return dispatch_size(type_size, [&](auto tag) {
 		using U = decltype(tag);
-		const uint32_t per = (uint32_t)g_tuning.scan_tiles_per_wg;
-		const dim3 grid((unsigned)((ntiles + per - 1) / per));
+		const dim3 grid((unsigned)ngroups);
 		const RangePred pred {blo, bspan, sbit};
 		uint32_t *bm = reinterpret_cast<uint32_t *>(d_bitmap);
-		const uint32_t nt = (uint32_t)ntiles;
 		const int tpl = g_tuning.templated_scan;
 #define ADAC_SCAN(OPN, VAL)                                                                                            \
-	hipLaunchKernelGGL((k_scan_agg<U, OPN, VAL>), grid, dim3(kWorkgroup), 0, s, d_descs, d_tiles, nt, per, tpl,       \
-	                   d_words, pred, d_validity, d_counts, bm)
+	hipLaunchKernelGGL((k_scan_agg<U, OPN, VAL>), grid, dim3(kWorkgroup), 0, s, d_groups, tpl, d_words, pred,         \
+	                   d_validity, d_counts, bm)
 		if (d_bitmap) {
 			if (d_validity) ADAC_SCAN(3, true); else ADAC_SCAN(3, false);
 		} else {

@@ -104,7 +104,7 @@ def test_random_columns(adac, oracle, gpu_ctx, seed):
                 assert np.array_equal(got[:span].astype(bool), expb) and not got[span:].any(), ("bitmap", templated, lo, hi)
     finally:
         adac.set_tuning("templated_scan", 1)
-        adac.set_tuning("scan_tiles_per_wg", 16)
+        adac.set_tuning("scan_tiles_per_wg", 0)
     # packed -> packed with the other padding choice: identical to a direct encode of what the column decodes to
     dst = adac.Layout(gpu_ctx, dtype, counts, offs)
     d_dst = gpu_ctx.alloc(dst.max_arena_words * 8 + 16).zero()

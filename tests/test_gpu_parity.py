@@ -148,7 +148,7 @@ def test_every_width(adac, oracle, gpu_ctx, dtype):
                     assert got == [int((v == kv).sum()) for v in seg_vals], (templated, group)
     finally:
         adac.set_tuning("templated_scan", 1)
-        adac.set_tuning("scan_tiles_per_wg", 16)
+        adac.set_tuning("scan_tiles_per_wg", 0)
 
 
 def test_signed_and_mixed_sign(adac, oracle, gpu_ctx):

@@ -57,7 +57,7 @@ def check_select(adac, ctx, lay, d_words, dtype, segs, offs, span, probes, valid
                     assert cnt == [int(exp[o:o + len(v)].sum()) for v, o in zip(segs, offs)]
     finally:
         adac.set_tuning("templated_scan", 1)
-        adac.set_tuning("scan_tiles_per_wg", 16)
+        adac.set_tuning("scan_tiles_per_wg", 0)
 
 
 @pytest.mark.parametrize("dtype", [np.uint64, np.int64, np.uint32, np.int32, np.uint16, np.int16, np.uint8, np.int8])

@@ -27,6 +27,10 @@ def main():
         ("lds x1", dict(base, templated_scan=0, scan_tiles_per_wg=1)),
         ("lds x8", dict(base, templated_scan=0, scan_tiles_per_wg=8)),
         ("templ x4", dict(base, templated_scan=1, scan_tiles_per_wg=4)),
+        ("templ x6", dict(base, templated_scan=1, scan_tiles_per_wg=6)),
+        ("templ x7", dict(base, templated_scan=1, scan_tiles_per_wg=7)),
+        ("templ x12", dict(base, templated_scan=1, scan_tiles_per_wg=12)),
+        ("templ x15", dict(base, templated_scan=1, scan_tiles_per_wg=15)),
         ("templ x8", dict(base, templated_scan=1, scan_tiles_per_wg=8)),
         ("templ x16", dict(base, templated_scan=1, scan_tiles_per_wg=16)),
         ("templ x32", dict(base, templated_scan=1, scan_tiles_per_wg=32)),

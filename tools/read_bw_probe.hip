@@ -1,0 +1,81 @@
+// Read-only HBM bandwidth ceiling probe for MI355X (diagnostic, not part of the library): sums a buffer with
+// 16-byte loads in a few launch shapes so the fused scans' GB/s can be read against what a bare streaming read
+// achieves on the same box.   build: hipcc --offload-arch=gfx950 -O3 -o /tmp/read_bw_probe tools/read_bw_probe.hip
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#define CK(x)                                                                                                          \
+	do {                                                                                                               \
+		hipError_t e = (x);                                                                                            \
+		if (e != hipSuccess) {                                                                                         \
+			std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e));                                                \
+			return 1;                                                                                                  \
+		}                                                                                                              \
+	} while (0)
+
+// each workgroup streams `chunks_per_wg` consecutive 16-byte chunks, 256 lanes wide, UNROLL loads in flight
+template <int UNROLL>
+__global__ __launch_bounds__(256) void k_stream(const uint4 *__restrict__ src, uint64_t nchunks, uint32_t chunks_per_wg,
+                                                uint64_t *__restrict__ out) {
+	const uint64_t lo = (uint64_t)blockIdx.x * chunks_per_wg;
+	uint64_t hi = lo + chunks_per_wg;
+	hi = hi < nchunks ? hi : nchunks;
+	uint32_t acc = 0;
+	uint64_t c = lo + threadIdx.x;
+	for (; c + (uint64_t)(UNROLL - 1) * 256 < hi; c += (uint64_t)UNROLL * 256) {
+		uint4 q[UNROLL];
+#pragma unroll
+		for (int u = 0; u < UNROLL; u++) q[u] = src[c + (uint64_t)u * 256];
+#pragma unroll
+		for (int u = 0; u < UNROLL; u++) acc += q[u].x ^ q[u].y ^ q[u].z ^ q[u].w;
+	}
+	for (; c < hi; c += 256) {
+		const uint4 q = src[c];
+		acc += q.x ^ q.y ^ q.z ^ q.w;
+	}
+	if (acc == 0x12345678u) out[0] = acc; // keeps the loads alive
+}
+
+int main() {
+	const uint64_t bytes = 1600ull << 20; // beyond the 256 MiB Infinity Cache
+	void *d = nullptr;
+	uint64_t *d_out = nullptr;
+	CK(hipMalloc(&d, bytes));
+	CK(hipMalloc((void **)&d_out, 8));
+	CK(hipMemset(d, 1, bytes));
+	hipEvent_t e0, e1;
+	CK(hipEventCreate(&e0));
+	CK(hipEventCreate(&e1));
+	const uint64_t nchunks = bytes / 16;
+	std::printf("{\"bytes\": %llu, \"cases\": [", (unsigned long long)bytes);
+	bool first = true;
+	for (uint32_t kb_per_wg : {4u, 16u, 32u, 64u, 128u, 512u, 2048u}) {
+		for (int unroll : {1, 2, 4}) {
+			const uint32_t cpw = kb_per_wg * 1024 / 16;
+			const unsigned grid = (unsigned)((nchunks + cpw - 1) / cpw);
+			auto launch = [&]() {
+				if (unroll == 1) hipLaunchKernelGGL(k_stream<1>, dim3(grid), dim3(256), 0, 0, (const uint4 *)d, nchunks, cpw, d_out);
+				if (unroll == 2) hipLaunchKernelGGL(k_stream<2>, dim3(grid), dim3(256), 0, 0, (const uint4 *)d, nchunks, cpw, d_out);
+				if (unroll == 4) hipLaunchKernelGGL(k_stream<4>, dim3(grid), dim3(256), 0, 0, (const uint4 *)d, nchunks, cpw, d_out);
+			};
+			for (int i = 0; i < 3; i++) launch();
+			CK(hipDeviceSynchronize());
+			CK(hipEventRecord(e0, 0));
+			const int reps = 10;
+			for (int i = 0; i < reps; i++) launch();
+			CK(hipEventRecord(e1, 0));
+			CK(hipEventSynchronize(e1));
+			float ms = 0;
+			CK(hipEventElapsedTime(&ms, e0, e1));
+			const double gbps = (double)bytes * reps / (ms * 1e-3) / 1e9;
+			std::printf("%s{\"kb_per_wg\": %u, \"loads_in_flight\": %d, \"workgroups\": %u, \"GBps\": %.0f}", first ? "" : ", ",
+			            kb_per_wg, unroll, grid, gbps);
+			first = false;
+		}
+	}
+	std::printf("]}\n");
+	return 0;
+}
