@@ -39,6 +39,20 @@ __global__ __launch_bounds__(256) void k_stream(const uint4 *__restrict__ src, u
 	if (acc == 0x12345678u) out[0] = acc; // keeps the loads alive
 }
 
+// decode-shaped traffic: every 16 bytes read become 32 bytes written (w = 32 -> u64), 256 lanes wide
+__global__ __launch_bounds__(256) void k_expand(const uint4 *__restrict__ src, uint64_t nchunks, uint32_t chunks_per_wg,
+                                                uint4 *__restrict__ dst) {
+	const uint64_t lo = (uint64_t)blockIdx.x * chunks_per_wg;
+	uint64_t hi = lo + chunks_per_wg;
+	hi = hi < nchunks ? hi : nchunks;
+	for (uint64_t c = lo + threadIdx.x; c < hi; c += 256) {
+		const uint4 q = src[c];
+		// lane-contiguous 32 bytes: two dwordx4 stores, like StoreSink's output chunks of two rounds
+		dst[2 * c] = make_uint4(q.x, 0u, q.y, 0u);
+		dst[2 * c + 1] = make_uint4(q.z, 0u, q.w, 0u);
+	}
+}
+
 int main() {
 	const uint64_t bytes = 1600ull << 20; // beyond the 256 MiB Infinity Cache
 	void *d = nullptr;
@@ -73,6 +87,32 @@ int main() {
 			const double gbps = (double)bytes * reps / (ms * 1e-3) / 1e9;
 			std::printf("%s{\"kb_per_wg\": %u, \"loads_in_flight\": %d, \"workgroups\": %u, \"GBps\": %.0f}", first ? "" : ", ",
 			            kb_per_wg, unroll, grid, gbps);
+			first = false;
+		}
+	}
+	std::printf("], \"expand_1_to_2\": [");
+	{
+		const uint64_t rd = 400ull << 20; // C2-like: 400 MB read, 800 MB written
+		void *d_dst = nullptr;
+		CK(hipMalloc(&d_dst, 2 * rd));
+		const uint64_t nch = rd / 16;
+		first = true;
+		for (uint32_t kb_per_wg : {2u, 4u, 8u, 16u, 64u}) {
+			const uint32_t cpw = kb_per_wg * 1024 / 16;
+			const unsigned grid = (unsigned)((nch + cpw - 1) / cpw);
+			for (int i = 0; i < 3; i++)
+				hipLaunchKernelGGL(k_expand, dim3(grid), dim3(256), 0, 0, (const uint4 *)d, nch, cpw, (uint4 *)d_dst);
+			CK(hipDeviceSynchronize());
+			CK(hipEventRecord(e0, 0));
+			const int reps = 10;
+			for (int i = 0; i < reps; i++)
+				hipLaunchKernelGGL(k_expand, dim3(grid), dim3(256), 0, 0, (const uint4 *)d, nch, cpw, (uint4 *)d_dst);
+			CK(hipEventRecord(e1, 0));
+			CK(hipEventSynchronize(e1));
+			float ms = 0;
+			CK(hipEventElapsedTime(&ms, e0, e1));
+			std::printf("%s{\"read_kb_per_wg\": %u, \"workgroups\": %u, \"total_GBps\": %.0f}", first ? "" : ", ", kb_per_wg,
+			            grid, 3.0 * (double)rd * reps / (ms * 1e-3) / 1e9);
 			first = false;
 		}
 	}
