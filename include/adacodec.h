@@ -130,6 +130,11 @@ int adac_set_tuning(const char *name, int value);
 
 /* ---------------------------------------------------------------------------------------------
  * Context and device memory.
+ *
+ * Threading: a context is one HIP stream and a layout caches launch tables on it, so calls that share a context
+ * (or a layout) are serialised by the caller — the host mirror does it with its pool lock, the way the
+ * reference serialises representation flips with bit_compression_lock (column_segment.cpp:162-167).  Different
+ * contexts (one per engine worker, or one per GPU) are independent; the host-only helpers are re-entrant.
  * ------------------------------------------------------------------------------------------- */
 
 /* Binds to HIP device `device`.  external_stream: a hipStream_t owned by the caller (e.g. the engine's or
