@@ -572,13 +572,15 @@ extern "C" adac_status adac_fetch_rows(adac_layout *l, const uint64_t *d_words, 
 // The scans' work items for the current grouping knob; the expansion kernel runs on the codec stream, so it is
 // ordered after the plan / descriptor upload that made it necessary.
 static adac_status ensure_scan_groups(adac_layout *l) {
-	// A segment's tiles are dealt EVENLY to ceil(tiles / target) workgroups.  Default target: ~24 K rows (12 tiles
-	// of u64, 6 of u32), so a 16-tile DuckDB segment becomes two groups of 8 tiles.  Measured (tools/ab_tuning.py,
+	// A segment's tiles are dealt EVENLY to ceil(tiles / target) workgroups.  Default target: 12 tiles of u64, 6 of
+	// u32 (~24 K rows), 8 of u16, 4 of u8 (64 K rows): a 16-tile DuckDB segment becomes two to four groups.  Measured (tools/ab_tuning.py,
 	// 400 M rows): a whole 32 767-row segment per workgroup puts the workgroups' packed streams and bitmap regions
 	// at the same power-of-two stride (32 KiB / 4 KiB) and costs 6-25 %; 16-24 K rows is the best of 4 .. 32 tiles
 	const uint32_t tile = adac::tile_values(l->type_size);
 	int per = adac::g_tuning.scan_tiles_per_wg;
-	if (per < 1) per = (int)(24576u / tile) < 1 ? 1 : (int)(24576u / tile);
+	if (per < 1) { // by type: best of 1 .. 32 tiles in tools/ab_tuning.py (u8 and u16 want more rows per workgroup)
+		per = l->type_size == 8 ? 12 : l->type_size == 4 ? 6 : l->type_size == 2 ? 8 : 4;
+	}
 	if (l->groups_tiles != per) {
 		std::vector<adac::ScanGroupRef> refs;
 		for (uint64_t s = 0; s < l->nseg; s++) {

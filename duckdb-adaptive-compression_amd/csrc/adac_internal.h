@@ -52,7 +52,7 @@ struct Tuning {
 	int persistent_unpack = 0;  // measured 5-15 % slower than one tile per workgroup (profiles/r01_ab_*.json)
 	int scan_probe = 0;         // diagnostic: fused-scan loop + loads only (no field walk)
 	int templated_scan = 1;     // width-templated register path of the fused scans for 4 <= w <= 32
-	int scan_tiles_per_wg = 0; // tiles per fused-scan workgroup; 0 = ~24 K rows (12 tiles of u64, 6 of u32, ...)
+	int scan_tiles_per_wg = 0; // tiles per fused-scan workgroup; 0 = by type (12 tiles of u64, 6 of u32, 8 of u16, 4 of u8)
 	int num_cus = 256;      // MI355X: 8 XCDs x 32 CUs
 	int blocks_per_cu = 8;  // 256-thread workgroups resident per CU (2048 threads, <= 16.5 KiB LDS each)
 };

@@ -124,7 +124,7 @@ adac_status adac_block_read(const void *block, uint64_t len, adac_segment_desc *
 /* values per device tile for a type (16 KiB of decoded output) */
 uint32_t adac_tile_values(int physical_type);
 /* Launch-shape knobs for in-process A/B measurement: "persistent_unpack", "templated_scan", "scan_probe" (0/1),
- * "scan_tiles_per_wg" (tiles per fused-scan workgroup; 0 = chosen by type, ~24 K rows), "blocks_per_cu",
+ * "scan_tiles_per_wg" (tiles per fused-scan workgroup; 0 = chosen by type), "blocks_per_cu",
  * "num_cus".  Results never depend on them.  Returns 0 if the name is known. */
 int adac_set_tuning(const char *name, int value);
 

@@ -26,6 +26,10 @@ def main():
     variants = [
         ("lds x1", dict(base, templated_scan=0, scan_tiles_per_wg=1)),
         ("lds x8", dict(base, templated_scan=0, scan_tiles_per_wg=8)),
+        ("templ auto", dict(base, templated_scan=1, scan_tiles_per_wg=0)),
+        ("templ x1", dict(base, templated_scan=1, scan_tiles_per_wg=1)),
+        ("templ x2", dict(base, templated_scan=1, scan_tiles_per_wg=2)),
+        ("templ x3", dict(base, templated_scan=1, scan_tiles_per_wg=3)),
         ("templ x4", dict(base, templated_scan=1, scan_tiles_per_wg=4)),
         ("templ x6", dict(base, templated_scan=1, scan_tiles_per_wg=6)),
         ("templ x7", dict(base, templated_scan=1, scan_tiles_per_wg=7)),
