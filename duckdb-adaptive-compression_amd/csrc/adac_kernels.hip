@@ -542,6 +542,7 @@ __device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint
 	uint4 q = seg16[Lc];
 	uint32_t e = reinterpret_cast<const uint32_t *>(seg16 + (Lc < clast ? Lc + 1 : clast))[0];
 	uint32_t adv = STRIDE;
+	uint32_t wave_count = 0; // wave-uniform (scalar) COUNT accumulator; lane 0 of the wave leaves the loop last
 	for (; Lw < lend; L += adv, Lw += adv) {
 		// selection: 64 chunks on inside a block, then on to this wave's next block
 		if (OP == 3) adv = blk_iter == kSelBlock - 1u ? (uint32_t)(kWorkgroup / 64) * kBlockChunks - (kSelBlock - 1u) * 64u : 64u;
@@ -564,6 +565,23 @@ __device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint
 		}
 		const uint32_t starting = (128u - o0 + (W - 1)) / W; // rows starting in the chunk: MAXV-1 or MAXV
 		const uint32_t lim = r1 > i0 ? r1 - i0 : 0u;
+		if (OP == 1 && !V) {
+			// COUNT through the scalar unit: when every active lane's chunk is interior, each field's compare
+			// lands in an SGPR pair and s_bcnt1 adds its population to a wave-uniform counter — three vector
+			// instructions per field (extract, subtract, compare) instead of five for the per-lane hit mask
+			if (__builtin_amdgcn_ballot_w64(starting > lim) == 0ull) {
+				uint32_t c = 0;
+#pragma unroll
+				for (int j = 0; j < MAXV - 1; j++) {
+					c += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((field_of<W>(nrm, j) - fr.flo) <= fr.span));
+				}
+				const bool last_hit = (field_of<W>(nrm, MAXV - 1) - fr.flo) <= fr.span;
+				c += (uint32_t)__popcll(
+				    __builtin_amdgcn_ballot_w64(last_hit && (128 % W == 0 || starting == (uint32_t)MAXV)));
+				wave_count += c;
+				continue;
+			}
+		}
 		if (PRED) {
 			// bit j of `hits` = row i0 + j satisfies the predicate: built top-down so that each field costs
 			// extract, subtract, compare and one add-with-carry (hits = 2 * hits + hit)
@@ -621,6 +639,7 @@ __device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint
 		}
 		acc += agg.total(nv, add);
 	}
+	if (OP == 1 && !V && (threadIdx.x & 63u) == 0u) acc += wave_count;
 }
 
 template <typename U, int OP, bool V>
