@@ -402,7 +402,22 @@ def main():
             "read_GBps": rd / (ms_sel * 1e-3) / 1e9, "bitmap_bytes": (args.rows + 7) // 8,
             "note": "includes clearing the bitmap (hipMemsetAsync) before the kernel",
         }
-        del d_bm
+        # scan-with-selection: decode only the rows the bitmap keeps (dense output + element ids)
+        nsel = int((vals <= median).sum())
+        d_gout = torch.empty(nsel + 16, dtype=torch.int64, device=col.d_vals.device)
+        d_gids = torch.empty(nsel + 16, dtype=torch.int64, device=col.d_vals.device)
+        torch.cuda.synchronize()
+        got = col.layout.unpack_selected(col.d_words, d_bm, d_gout, d_gids)
+        keep = np.flatnonzero(vals <= median)
+        if got != nsel or not torch.equal(d_gout[:nsel].cpu(), torch.from_numpy(vals[keep].view(np.int64))) \
+                or not torch.equal(d_gids[:nsel].cpu(), torch.from_numpy(keep.astype(np.int64))):
+            raise RuntimeError("parity failure: unpack_selected")
+        ms_g = time_launches(ctx, lambda: col.layout.unpack_selected(col.d_words, d_bm, d_gout, d_gids, False), args.steps)
+        result["fused_scan"]["unpack_selected"] = {
+            "selected_rows": nsel, "ms": ms_g, "selected_values_per_s": nsel / (ms_g * 1e-3),
+            "scanned_values_per_s": args.rows / (ms_g * 1e-3),
+            "note": "values + element ids of the selected rows, dense, row order (popcount, prefix, gather kernels)"}
+        del d_bm, d_gout, d_gids
         # A6: point fetch (SuccinctFetchRow) — 16 M uniformly random (segment, row) look-ups in one launch
         nf = 1 << 24
         frng = np.random.default_rng(99)

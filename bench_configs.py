@@ -224,6 +224,15 @@ def q6_packed(adac, n=59_986_052):
         for _ in range(reps):
             fn()
         steps[name] = ctx.timer_stop() / reps
+    # filter then project: only the surviving rows of l_extendedprice are decoded
+    d_sel = ctx.alloc(int(m.sum()) * 4 + 64)
+    lay, w, _ = enc["l_extendedprice"]
+    got = lay.unpack_selected(w, bm[2], d_sel)
+    assert got == int(m.sum()) and np.array_equal(d_sel.download(np.int32, got), cols["l_extendedprice"][m])
+    ctx.timer_start()
+    for _ in range(reps):
+        lay.unpack_selected(w, bm[2], d_sel, None, False)
+    steps["project_price_selected"] = ctx.timer_stop() / reps
     d_out = ctx.alloc(n * 4 + 64)
     ctx.timer_start()
     for _ in range(reps):

@@ -131,6 +131,7 @@ SIGNATURES = {
     "adac_scan_count_between": (_int, [_vp, _vp, _u64, _u64, _vp]),
     "adac_scan_sum_valid": (_int, [_vp, _vp, _vp, _vp]),
     "adac_scan_select_between": (_int, [_vp, _vp, _vp, _u64, _u64, _vp, _vp]),
+    "adac_unpack_selected": (_int, [_vp, _vp, _vp, _vp, _vp, C.POINTER(_u64)]),
     "adac_scan_count_between_valid": (_int, [_vp, _vp, _vp, _u64, _u64, _vp]),
     "adac_bp_layout_create": (_int, [_vp, _int, _vp, _vp, _vp, _u64, _P(_vp)]),
     "adac_bp_layout_destroy": (None, [_vp]),
@@ -415,6 +416,14 @@ class Layout:
         """Selection bitmap over the element index space (ceil(value_span / 64) words) + per-segment hit counts."""
         _check(lib().adac_scan_select_between(self._h, _dptr(d_words), _dptr(d_validity), lo & NO_MIN, hi & NO_MIN,
                                               _dptr(d_bitmap), _dptr(d_counts)), "adac_scan_select_between")
+
+    def unpack_selected(self, d_words, d_bitmap, d_out, d_out_ids=None, want_total=True):
+        """Values (and optionally element indices) of the rows whose bitmap bit is set, dense, in row order.
+        Returns the number of rows written (None when want_total is False: the call then stays asynchronous)."""
+        total = _u64()
+        _check(lib().adac_unpack_selected(self._h, _dptr(d_words), _dptr(d_bitmap), _dptr(d_out), _dptr(d_out_ids),
+                                          C.byref(total) if want_total else None), "adac_unpack_selected")
+        return total.value if want_total else None
 
     def scan_count_eq(self, d_words, key, d_counts):
         _check(lib().adac_scan_count_eq(self._h, _dptr(d_words), key & NO_MIN, _dptr(d_counts)), "adac_scan_count_eq")

@@ -56,6 +56,10 @@ struct adac_layout {
 	uint64_t ngroups = 0;
 	int groups_tiles = 0;
 	bool groups_dirty = true;
+	// scratch of adac_unpack_selected: selected rows per tile, their exclusive prefix, block totals + grand total
+	uint32_t *d_tile_cnt = nullptr;
+	uint64_t *d_tile_off = nullptr;
+	uint64_t *d_block_tot = nullptr;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -389,6 +393,9 @@ extern "C" void adac_layout_destroy(adac_layout *l) {
 	if (l->d_descs) (void)hipFree(l->d_descs);
 	if (l->d_tiles) (void)hipFree(l->d_tiles);
 	if (l->d_minmax) (void)hipFree(l->d_minmax);
+	if (l->d_tile_cnt) (void)hipFree(l->d_tile_cnt);
+	if (l->d_tile_off) (void)hipFree(l->d_tile_off);
+	if (l->d_block_tot) (void)hipFree(l->d_block_tot);
 	if (l->d_group_refs) (void)hipFree(l->d_group_refs);
 	if (l->d_groups) (void)hipFree(l->d_groups);
 	delete l;
@@ -677,6 +684,26 @@ extern "C" adac_status adac_scan_count_between_valid(adac_layout *l, const uint6
 extern "C" adac_status adac_scan_select_between(adac_layout *l, const uint64_t *d_words, const uint64_t *d_validity,
                                                 uint64_t lo, uint64_t hi, uint64_t *d_bitmap, uint64_t *d_counts) {
 	return scan_range(l, d_words, d_validity, lo, hi, d_counts, d_bitmap, true);
+}
+
+extern "C" adac_status adac_unpack_selected(adac_layout *l, const uint64_t *d_words, const uint64_t *d_bitmap,
+                                            void *d_out, uint64_t *d_out_ids, uint64_t *total_out) {
+	if (!l || (l->total_values && (!d_words || !d_bitmap || !d_out))) return ADAC_ERR_INVALID_ARGUMENT;
+	if (!aligned16(d_words)) return ADAC_ERR_INVALID_ARGUMENT;
+	ADAC_HIP(hipSetDevice(l->ctx->device));
+	if (!l->d_tile_cnt) {
+		const uint64_t nt = l->ntiles ? l->ntiles : 1;
+		ADAC_HIP(hipMalloc((void **)&l->d_tile_cnt, nt * sizeof(uint32_t)));
+		ADAC_HIP(hipMalloc((void **)&l->d_tile_off, nt * sizeof(uint64_t)));
+		ADAC_HIP(hipMalloc((void **)&l->d_block_tot, ((nt + 1023) / 1024 + 1) * sizeof(uint64_t)));
+	}
+	const uint64_t nblocks = (l->ntiles + 1023) / 1024;
+	uint64_t *d_total = l->d_block_tot + nblocks; // the spare slot after the block totals
+	ADAC_HIP(adac::launch_gather_selected(l->ctx->stream, l->type_size, l->d_descs, l->d_tiles, l->ntiles, d_words,
+	                                      d_bitmap, l->d_tile_cnt, l->d_tile_off, l->d_block_tot, d_out, d_out_ids,
+	                                      d_total));
+	if (total_out) return adac_memcpy_d2h(l->ctx, total_out, d_total, sizeof(uint64_t));
+	return ADAC_OK;
 }
 
 extern "C" adac_status adac_scan_count_eq(adac_layout *l, const uint64_t *d_words, uint64_t key, uint64_t *d_counts) {

@@ -86,6 +86,10 @@ hipError_t launch_repack(hipStream_t s, uint32_t type_size, uint64_t null_bits, 
                          const uint64_t *d_src_words, const uint64_t *d_validity, uint64_t *d_dst_words);
 hipError_t launch_expand_groups(hipStream_t s, const adac_segment_desc *d_descs, const ScanGroupRef *d_refs,
                                 uint64_t ngroups, ScanGroup *d_groups);
+hipError_t launch_gather_selected(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs,
+                                  const TileRef *d_tiles, uint64_t ntiles, const uint64_t *d_words,
+                                  const uint64_t *d_bitmap, uint32_t *d_tile_cnt, uint64_t *d_tile_off,
+                                  uint64_t *d_block_tot, void *d_out, uint64_t *d_out_ids, uint64_t *d_total);
 hipError_t launch_scan_sum(hipStream_t s, uint32_t type_size, const ScanGroup *d_groups, uint64_t ngroups,
                            const uint64_t *d_words, const uint64_t *d_validity, uint64_t sbit, uint64_t *d_sums);
 hipError_t launch_scan_count_range(hipStream_t s, uint32_t type_size, const ScanGroup *d_groups, uint64_t ngroups,

@@ -458,11 +458,14 @@ struct ChunkSum {
 	}
 };
 
-// `bits` validity bits starting at element index e (bit j of the result = element e + j), bits <= 32
-__device__ __forceinline__ uint32_t validity_window(const uint64_t *__restrict__ validity, uint64_t e) {
+// `nbits` (<= 32) mask bits starting at element index e: bit j of the result = element e + j; bits past nbits are
+// unspecified.  The second word is read only when the wanted bits reach into it, so a mask of exactly
+// ceil(span / 64) words is never over-read as long as nbits is clipped to the rows that exist.
+__device__ __forceinline__ uint32_t validity_window(const uint64_t *__restrict__ validity, uint64_t e, uint32_t nbits) {
+	if (nbits == 0u) return 0u; // nothing wanted: e may lie past the mask
 	const uint32_t sh = (uint32_t)(e & 63);
 	uint64_t wnd = validity[e >> 6] >> sh;
-	if (sh > 32) wnd |= validity[(e >> 6) + 1] << (64 - sh);
+	if (sh + nbits > 64u) wnd |= validity[(e >> 6) + 1] << (64 - sh);
 	return (uint32_t)wnd;
 }
 
@@ -594,7 +597,7 @@ __device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint
 			hits &= have >= 32u ? 0xffffffffu : ((1u << have) - 1u);
 			const uint32_t at = i0 < r1 ? i0 : r1; // keeps a lane's element range inside this run
 			// NULL rows (DuckDB validity mask over the element index space) take no part
-			if (V) hits &= validity_window(validity, d.val_off + at);
+			if (V) hits &= validity_window(validity, d.val_off + at, have);
 			acc += (uint32_t)__popc(hits);
 			if (OP == 3) {
 				if (blk_iter == 0) {
@@ -619,8 +622,8 @@ __device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint
 		ChunkSum<W> agg;
 		uint32_t nv = 0;
 		if (V) {
-			const uint32_t vbits = validity_window(validity, d.val_off + i0);
 			const uint32_t have = starting < lim ? starting : lim;
+			const uint32_t vbits = validity_window(validity, d.val_off + i0, have);
 #pragma unroll
 			for (int j = 0; j < MAXV; j++) {
 				if ((uint32_t)j < have) agg.add_if(field_of<W>(nrm, j), (vbits >> j) & 1u);
@@ -717,7 +720,8 @@ __global__ __launch_bounds__(kWorkgroup, 6) void k_scan_agg(const ScanGroup *__r
 			const uint64_t elem0 = d.val_off + first;
 			auto sink = [&](int32_t base, const U *vals, bool full) {
 				constexpr int KK = 16 / (int)sizeof(U);
-				const uint32_t vbits = V ? validity_window(validity, elem0 + (uint32_t)(base < 0 ? 0 : base)) : 0xffffffffu;
+				const uint32_t rows_here = full || n - (uint32_t)base >= (uint32_t)KK ? (uint32_t)KK : n - (uint32_t)base;
+				const uint32_t vbits = V ? validity_window(validity, elem0 + (uint32_t)base, rows_here) : 0xffffffffu;
 				if (OP == 3) { // decode_run walks with align 0: base >= 0, lanes ascending
 					uint32_t hits = 0;
 #pragma unroll
@@ -1135,7 +1139,8 @@ __global__ __launch_bounds__(kWorkgroup) void k_analyze_packed(const adac_segmen
 	uint64_t mn = ~0ull, mx = 0;
 	auto sink = [&](int32_t base, const U *v, bool full) { // align 0: base >= 0
 		constexpr int K = 16 / (int)sizeof(U);
-		const uint32_t vbits = validity ? validity_window(validity, t.elem0 + (uint32_t)base) : 0xffffffffu;
+		const uint32_t rows_here = full || t.n - (uint32_t)base >= (uint32_t)K ? (uint32_t)K : t.n - (uint32_t)base;
+		const uint32_t vbits = validity ? validity_window(validity, t.elem0 + (uint32_t)base, rows_here) : 0xffffffffu;
 #pragma unroll
 		for (int j = 0; j < K; j++) {
 			if (!full && (uint32_t)(base + j) >= t.n) continue;
@@ -1190,7 +1195,8 @@ __global__ __launch_bounds__(kWorkgroup) void k_repack(const adac_segment_desc *
 	__syncthreads();
 	auto sink = [&](int32_t base, const U *v, bool full) {
 		constexpr int K = 16 / (int)sizeof(U);
-		const uint32_t vbits = validity ? validity_window(validity, t.elem0 + (uint32_t)base) : 0xffffffffu;
+		const uint32_t rows_here = full || t.n - (uint32_t)base >= (uint32_t)K ? (uint32_t)K : t.n - (uint32_t)base;
+		const uint32_t vbits = validity ? validity_window(validity, t.elem0 + (uint32_t)base, rows_here) : 0xffffffffu;
 		if (full) {
 			U o[K];
 #pragma unroll
@@ -1264,6 +1270,7 @@ hipError_t dispatch_size(uint32_t type_size, F &&f) {
 }
 
 #include "adac_bitpacking.inl"
+#include "adac_select_gather.inl"
 
 unsigned persistent_grid(uint64_t ntiles) {
 	const uint64_t cap = (uint64_t)g_tuning.num_cus * (uint64_t)g_tuning.blocks_per_cu;
@@ -1486,6 +1493,27 @@ hipError_t launch_bp_fetch(hipStream_t s, uint32_t type_size, const uint64_t *d_
 		hipLaunchKernelGGL(k_bp_fetch<U>, dim3((unsigned)((n + kWorkgroup - 1) / kWorkgroup)), dim3(kWorkgroup), 0, s,
 		                   d_block_offs, static_cast<const uint8_t *>(d_blocks), d_segs, d_rows, n,
 		                   static_cast<U *>(d_out));
+		return hipGetLastError();
+	});
+}
+
+hipError_t launch_gather_selected(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs,
+                                  const TileRef *d_tiles, uint64_t ntiles, const uint64_t *d_words,
+                                  const uint64_t *d_bitmap, uint32_t *d_tile_cnt, uint64_t *d_tile_off,
+                                  uint64_t *d_block_tot, void *d_out, uint64_t *d_out_ids, uint64_t *d_total) {
+	if (ntiles == 0) return hipMemsetAsync(d_total, 0, sizeof(uint64_t), s);
+	return dispatch_size(type_size, [&](auto tag) {
+		using U = decltype(tag);
+		const unsigned per = kWorkgroup / 64;
+		hipLaunchKernelGGL(k_tile_popc<U>, dim3((unsigned)((ntiles + per - 1) / per)), dim3(kWorkgroup), 0, s, d_descs,
+		                   d_tiles, (uint32_t)ntiles, d_bitmap, d_tile_cnt);
+		const uint64_t nblocks = (ntiles + kScanBlock - 1) / kScanBlock;
+		hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)nblocks), dim3(kScanBlock), 0, s, d_tile_cnt, ntiles, d_tile_off,
+		                   d_block_tot);
+		hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(kScanBlock), 0, s, d_block_tot, nblocks, d_total);
+		hipLaunchKernelGGL(k_scan_fixup, dim3((unsigned)nblocks), dim3(kScanBlock), 0, s, d_tile_off, ntiles, d_block_tot);
+		hipLaunchKernelGGL(k_gather<U>, dim3((unsigned)ntiles), dim3(kWorkgroup), 0, s, d_descs, d_tiles, d_words,
+		                   d_bitmap, d_tile_off, static_cast<U *>(d_out), d_out_ids);
 		return hipGetLastError();
 	});
 }

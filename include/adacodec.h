@@ -284,6 +284,16 @@ adac_status adac_scan_count_between_valid(adac_layout *l, const uint64_t *d_word
 adac_status adac_scan_select_between(adac_layout *l, const uint64_t *d_words, const uint64_t *d_validity, uint64_t lo,
                                      uint64_t hi, uint64_t *d_bitmap, uint64_t *d_counts);
 
+/* Materialise only the selected rows: d_out receives, densely and in row order (segment by segment), the values of
+ * the rows whose bit is set in d_bitmap (the result of adac_scan_select_between, or any mask over the element index
+ * space); d_out_ids, if not NULL, receives their element indices (val_off + row).  *total_out, if not NULL, is set
+ * to the number of rows written (this makes the call synchronous); d_out must hold at least that many values —
+ * the sum of the select's d_counts, or total_values in the worst case.  The scan-with-selection half of
+ * ColumnSegment::FilterSelection (column_segment.cpp:575-844): a tile is decoded once, rows that did not pass are
+ * never written. */
+adac_status adac_unpack_selected(adac_layout *l, const uint64_t *d_words, const uint64_t *d_bitmap, void *d_out,
+                                 uint64_t *d_out_ids, uint64_t *total_out);
+
 /* ---------------------------------------------------------------------------------------------
  * DuckDB BITPACKING segments — the persistent counterpart of the succinct codec, decode side.
  * A segment is the block image DuckDB's checkpoint writes (src/storage/compression/bitpacking.cpp:357-538):

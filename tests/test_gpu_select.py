@@ -152,3 +152,75 @@ def test_conjunction_and_aggregate_without_materialising(adac, oracle, gpu_ctx):
     got = d_sum.download(np.uint64, len(counts)).tolist()
     assert got == [wide_sum(cols["price"][o:o + int(c)][m[o:o + int(c)]]) for o, c in zip(offs, counts)]
     assert m.sum() > 1000
+
+
+@pytest.mark.parametrize("dtype", [np.uint64, np.int32, np.uint16, np.int8])
+def test_unpack_selected_materialises_only_the_selected_rows(adac, oracle, gpu_ctx, dtype):
+    """adac_unpack_selected: values + element ids of the rows a bitmap keeps, dense and in row order, for ragged
+    segments at unaligned offsets, every width class, empty and full selections."""
+    dtype = np.dtype(dtype)
+    tb = 8 * dtype.itemsize
+    rng = np.random.default_rng(70 + tb)
+    tile = adac.tile_values(dtype)
+    widths = sorted({1, 3, 5, 8, 13, 16, 27, 33, 50, tb} & set(range(1, tb + 1)))
+    counts = [int(rng.integers(1, 3 * tile)) if i % 2 else 2 * tile for i in range(len(widths))] + [1, 0, tile + 7]
+    segs = [make_values(rng, dtype, c, w) for c, w in zip(counts, widths + [2, 2, 4])]
+    counts = np.array(counts, dtype=np.uint32)
+    offs, run = [], 0
+    for i, c in enumerate(counts):
+        run += (0, 5, 64, 1)[i % 4]
+        offs.append(run)
+        run += int(c)
+    span = run
+    lay, d_words, _, _, _ = run_encode_decode(adac, oracle, gpu_ctx, dtype, counts, segs,
+                                              val_offs=np.array(offs, dtype=np.uint64))
+    total_rows = int(counts.sum())
+    d_out = gpu_ctx.alloc(total_rows * dtype.itemsize + 64)
+    d_ids = gpu_ctx.alloc(total_rows * 8 + 64)
+    for density in (0.0, 0.003, 0.3, 1.0):
+        sel = np.zeros(span, dtype=bool)
+        for v, o in zip(segs, offs):
+            sel[o:o + len(v)] = rng.random(len(v)) < density if 0 < density < 1 else bool(density)
+        if density == 0.3:
+            sel[offs[0]:offs[0] + 70] = True       # runs crossing bitmap words
+        d_bm = gpu_ctx.upload(pack_mask(sel, span)[:(span + 63) // 64])   # exactly ceil(span / 64) words
+        n = lay.unpack_selected(d_words, d_bm, d_out, d_ids)
+        exp_vals = np.concatenate([v[sel[o:o + len(v)]] for v, o in zip(segs, offs)])
+        exp_ids = np.concatenate([o + np.flatnonzero(sel[o:o + len(v)]) for v, o in zip(segs, offs)]).astype(np.uint64)
+        assert n == len(exp_vals), (dtype, density)
+        assert np.array_equal(d_out.download(dtype, max(n, 1))[:n], exp_vals), (dtype, density)
+        assert np.array_equal(d_ids.download(np.uint64, max(n, 1))[:n], exp_ids), (dtype, density)
+        n2 = lay.unpack_selected(d_words, d_bm, d_out)              # without ids
+        assert n2 == n and np.array_equal(d_out.download(dtype, max(n, 1))[:n], exp_vals)
+
+
+def test_filter_then_project_pipeline(adac, oracle, gpu_ctx):
+    """SELECT price FROM t WHERE shipdate BETWEEN .. AND quantity < 24 on packed columns: two chained filter scans,
+    then only the surviving rows of a third column are decoded."""
+    rng = np.random.default_rng(9)
+    n = 700_001
+    counts = adac.appender_segment_counts(n, 4)
+    cols = {"shipdate": rng.integers(8000, 10600, size=n).astype(np.int32),
+            "quantity": rng.integers(1, 51, size=n).astype(np.int32),
+            "price": rng.integers(90_000, 10_500_000, size=n).astype(np.int32)}
+    enc = {}
+    for name, v in cols.items():
+        lay = adac.Layout(gpu_ctx, np.int32, counts)
+        d_words = gpu_ctx.alloc(lay.max_arena_words * 8 + 16).zero()
+        lay.encode(gpu_ctx.upload(v), d_words)
+        enc[name] = (lay, d_words)
+    nw = (n + 63) // 64
+    bm0, bm1 = gpu_ctx.alloc(nw * 8), gpu_ctx.alloc(nw * 8)
+    d_cnt = gpu_ctx.alloc(len(counts) * 8)
+    enc["shipdate"][0].scan_select_between(enc["shipdate"][1], 8766, 9130, bm0, d_cnt)
+    enc["quantity"][0].scan_select_between(enc["quantity"][1], bit_pattern(np.iinfo(np.int32).min, np.int32), 23, bm1,
+                                           d_cnt, bm0)
+    m = (cols["shipdate"] >= 8766) & (cols["shipdate"] <= 9130) & (cols["quantity"] < 24)
+    hits = int(d_cnt.download(np.uint64, len(counts)).sum())
+    assert hits == int(m.sum())
+    d_out = gpu_ctx.alloc(hits * 4 + 64)
+    d_ids = gpu_ctx.alloc(hits * 8 + 64)
+    got = enc["price"][0].unpack_selected(enc["price"][1], bm1, d_out, d_ids)
+    assert got == hits
+    assert np.array_equal(d_out.download(np.int32, hits), cols["price"][m])
+    assert np.array_equal(d_ids.download(np.uint64, hits), np.flatnonzero(m).astype(np.uint64))
