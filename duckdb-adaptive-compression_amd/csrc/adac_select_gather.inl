@@ -113,8 +113,14 @@ __global__ __launch_bounds__(kWorkgroup) void k_gather(const adac_segment_desc *
 	if ((threadIdx.x & 63u) == 63u) wave_tot[threadIdx.x >> 6] = incl;
 	const uint32_t bit0 = stage_packed(words + t.d.word_off, t.first, t.n, t.d.width, lds);
 	__syncthreads();
-	uint32_t before = incl - run;
-	for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) before += wave_tot[w];
+	uint32_t before = incl - run, total = 0;
+#pragma unroll
+	for (uint32_t w = 0; w < kWorkgroup / 64; w++) {
+		const uint32_t tw = wave_tot[w];
+		if (w < (threadIdx.x >> 6)) before += tw;
+		total += tw;
+	}
+	if (total == 0) return; // nothing selected in this tile (workgroup-uniform): no decode at all
 #pragma unroll
 	for (int k = 0; k < PER_LANE; k++) chunk_off[threadIdx.x * PER_LANE + k] = (uint16_t)(before + cnt[k]);
 	__syncthreads();
