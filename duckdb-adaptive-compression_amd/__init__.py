@@ -126,6 +126,10 @@ SIGNATURES = {
     "adac_unpack": (_int, [_vp, _vp, _vp]),
     "adac_unpack_range": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _u64]),
     "adac_fetch_rows": (_int, [_vp, _vp, _vp, _vp, _u64, _vp]),
+    "adac_capture_begin": (_int, [_vp]),
+    "adac_capture_end": (_int, [_vp, C.POINTER(_vp)]),
+    "adac_graph_launch": (_int, [_vp]),
+    "adac_graph_destroy": (None, [_vp]),
     "adac_scan_sum": (_int, [_vp, _vp, _vp]),
     "adac_scan_count_eq": (_int, [_vp, _vp, _u64, _vp]),
     "adac_scan_count_between": (_int, [_vp, _vp, _u64, _u64, _vp]),
@@ -306,6 +310,17 @@ class Context:
         arr = np.ascontiguousarray(arr)
         return DeviceBuffer(self, max(arr.nbytes, 16)).upload(arr)
 
+    def capture(self, fn):
+        """Run fn() (enqueue calls on this context only, after an eager warm-up) under HIP-graph capture."""
+        _check(lib().adac_capture_begin(self._h), "adac_capture_begin")
+        try:
+            fn()
+        finally:
+            g = _vp()
+            st = lib().adac_capture_end(self._h, C.byref(g))
+        _check(st, "adac_capture_end")
+        return Graph(g)
+
     def timer_start(self):
         _check(lib().adac_timer_start(self._h), "adac_timer_start")
 
@@ -313,6 +328,27 @@ class Context:
         ms = C.c_float()
         _check(lib().adac_timer_stop(self._h, C.byref(ms)), "adac_timer_stop")
         return ms.value
+
+
+class Graph:
+    """A captured sequence of codec calls (adac_graph): launch() replays it on the context's stream."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def launch(self):
+        _check(lib().adac_graph_launch(self._h), "adac_graph_launch")
+
+    def close(self):
+        if self._h:
+            lib().adac_graph_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pragma: no cover
+            pass
 
 
 class Layout:

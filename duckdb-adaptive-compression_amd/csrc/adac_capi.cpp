@@ -62,6 +62,8 @@ struct adac_layout {
 	uint64_t *d_block_tot = nullptr;
 };
 
+static adac_status descs_changed(adac_layout *l);
+
 // ------------------------------------------------------------------------------------------------
 // host-only helpers
 // ------------------------------------------------------------------------------------------------
@@ -318,6 +320,61 @@ extern "C" adac_status adac_timer_stop(adac_ctx *c, float *ms) {
 	return ADAC_OK;
 }
 
+// Capture of a sequence of enqueue calls into a HIP graph: short pipelines (a multi-column filter + aggregate is
+// a dozen memsets and kernels of 20-50 us each) replay with one launch instead of one per node.
+struct adac_graph {
+	adac_ctx *ctx = nullptr;
+	hipGraph_t graph = nullptr;
+	hipGraphExec_t exec = nullptr;
+};
+
+extern "C" adac_status adac_capture_begin(adac_ctx *c) {
+	if (!c) return ADAC_ERR_INVALID_ARGUMENT;
+	ADAC_HIP(hipSetDevice(c->device));
+	ADAC_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+	return ADAC_OK;
+}
+
+extern "C" adac_status adac_capture_end(adac_ctx *c, adac_graph **out) {
+	if (!c || !out) return ADAC_ERR_INVALID_ARGUMENT;
+	*out = nullptr;
+	ADAC_HIP(hipSetDevice(c->device));
+	hipGraph_t g = nullptr;
+	ADAC_HIP(hipStreamEndCapture(c->stream, &g));
+	hipGraphExec_t exec = nullptr;
+	hipError_t e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+	if (e != hipSuccess) {
+		(void)hipGraphDestroy(g);
+		return fail_hip(e, "hipGraphInstantiate");
+	}
+	adac_graph *h = new (std::nothrow) adac_graph();
+	if (!h) {
+		(void)hipGraphExecDestroy(exec);
+		(void)hipGraphDestroy(g);
+		return ADAC_ERR_OUT_OF_MEMORY;
+	}
+	h->ctx = c;
+	h->graph = g;
+	h->exec = exec;
+	*out = h;
+	return ADAC_OK;
+}
+
+extern "C" adac_status adac_graph_launch(adac_graph *g) {
+	if (!g) return ADAC_ERR_INVALID_ARGUMENT;
+	ADAC_HIP(hipSetDevice(g->ctx->device));
+	ADAC_HIP(hipGraphLaunch(g->exec, g->ctx->stream));
+	return ADAC_OK;
+}
+
+extern "C" void adac_graph_destroy(adac_graph *g) {
+	if (!g) return;
+	(void)hipSetDevice(g->ctx->device);
+	if (g->exec) (void)hipGraphExecDestroy(g->exec);
+	if (g->graph) (void)hipGraphDestroy(g->graph);
+	delete g;
+}
+
 // ------------------------------------------------------------------------------------------------
 // layout
 // ------------------------------------------------------------------------------------------------
@@ -423,8 +480,7 @@ extern "C" adac_status adac_layout_set_descs(adac_layout *l, const adac_segment_
 		                        l->ctx->stream));
 		ADAC_HIP(hipStreamSynchronize(l->ctx->stream));
 	}
-	l->groups_dirty = true;
-	return ADAC_OK;
+	return descs_changed(l);
 }
 
 extern "C" adac_status adac_layout_get_descs(adac_layout *l, adac_segment_desc *descs) {
@@ -442,6 +498,18 @@ extern "C" adac_status adac_layout_get_minmax(adac_layout *l, uint64_t *minmax) 
 // ------------------------------------------------------------------------------------------------
 
 static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Descriptors changed (plan / set_descs): re-expand the scans' work-item records in stream order right away when
+// the table exists, so that a captured graph replayed after a re-encode reads current records; otherwise the
+// next scan builds the table.
+static adac_status descs_changed(adac_layout *l) {
+	l->groups_dirty = true;
+	if (l->d_groups && l->groups_tiles > 0) {
+		ADAC_HIP(adac::launch_expand_groups(l->ctx->stream, l->d_descs, l->d_group_refs, l->ngroups, l->d_groups));
+		l->groups_dirty = false;
+	}
+	return ADAC_OK;
+}
 
 extern "C" adac_status adac_analyze(adac_layout *l, const void *d_vals, const uint64_t *d_validity, int rule) {
 	if (!l || (!d_vals && l->total_values) || (rule != ADAC_RULE_APPEND && rule != ADAC_RULE_RECOMPACT))
@@ -484,8 +552,7 @@ extern "C" adac_status adac_plan(adac_layout *l, int rule, int pad_to_byte) {
 	ADAC_HIP(hipSetDevice(l->ctx->device));
 	ADAC_HIP(adac::launch_plan(l->ctx->stream, l->type_size, rule, pad_to_byte ? 1 : 0, l->d_descs, l->d_minmax,
 	                           l->nseg));
-	l->groups_dirty = true;
-	return ADAC_OK;
+	return descs_changed(l);
 }
 
 extern "C" adac_status adac_pack(adac_layout *l, const void *d_vals, const uint64_t *d_validity, uint64_t *d_words) {
