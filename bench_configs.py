@@ -261,6 +261,42 @@ def q6_packed(adac, n=59_986_052):
     return out
 
 
+def c1_lookups(adac, wl, n=10_000_000, nlookups=10_000):
+    """C1 (benchmark/micro/succinct/zipf_distribution.cpp:13-48): t1(i UINTEGER) with i = 0..N-1, compacted, then
+    `SELECT i FROM t1 WHERE i == k` for Zipf(N, 1.0) keys (mt19937, seed 42).  Each look-up is one fused
+    COUNT(== k) over the packed column: segments whose [min, min + 2^w) cannot hold k are skipped by the kernel
+    (one 64-byte record read each), so a look-up costs a launch plus one segment's scan."""
+    ctx = adac.Context(0)
+    vals = np.arange(n, dtype=np.uint32)
+    counts = adac.appender_segment_counts(n, 4)
+    lay = adac.Layout(ctx, np.uint32, counts)
+    d_words = ctx.alloc(lay.max_arena_words * 8 + 16).zero()
+    lay.encode(ctx.upload(vals), d_words)
+    ctx.sync()
+    descs = lay.get_descs()
+    keys = (wl.zipf_column(nlookups, np.uint32, domain=n, skew=1.0, seed=42, threads=1).astype(np.int64) - 1) % n
+    d_cnt = ctx.alloc(len(counts) * 8)
+    lay.scan_count_eq(d_words, int(keys[0]), d_cnt)
+    ctx.sync()
+    t0 = time.perf_counter()
+    for k in keys:
+        lay.scan_count_eq(d_words, int(k), d_cnt)
+    ctx.sync()
+    wall = time.perf_counter() - t0
+    hits = int(d_cnt.download(np.uint64, len(counts)).sum())
+    assert hits == 1
+    ctx.timer_start()
+    for k in keys[:2000]:
+        lay.scan_count_eq(d_words, int(k), d_cnt)
+    dev_ms = ctx.timer_stop() / 2000
+    out = {"rows": n, "segments": int(len(counts)), "max_width": int(descs["width"].max()),
+           "packed_bytes": int(((descs["count"].astype(np.uint64) * descs["width"] + 63) // 64 * 8).sum()),
+           "lookups": nlookups, "lookups_per_s_wall": nlookups / wall, "device_us_per_lookup": dev_ms * 1e3,
+           "note": "one fused COUNT(== k) launch per look-up, results stay on the device; wall = Python loop included"}
+    ctx.close()
+    return out
+
+
 def main():
     adac = importlib.import_module(PKG)
     adac.build()
@@ -269,7 +305,8 @@ def main():
     wl = importlib.import_module(PKG + ".workload")
     only = sys.argv[1:]
     jobs = {"plugin_scan": lambda: plugin_scan(host, lay), "adaptive": lambda: adaptive(host, wl),
-            "bitpacking_scan": lambda: bitpacking_scan(adac), "q6_packed": lambda: q6_packed(adac)}
+            "bitpacking_scan": lambda: bitpacking_scan(adac), "q6_packed": lambda: q6_packed(adac),
+            "c1_lookups": lambda: c1_lookups(adac, wl)}
     res = {k: f() for k, f in jobs.items() if not only or k in only}
     print(json.dumps(res))
 

@@ -10,6 +10,7 @@ Import with importlib (the directory name is not a Python identifier):
 import ctypes as C
 import os
 import subprocess
+import weakref
 
 import numpy as np
 
@@ -248,6 +249,7 @@ class DeviceBuffer:
         p = _vp()
         _check(lib().adac_dev_alloc(ctx._h, nbytes, C.byref(p)), "adac_dev_alloc")
         self.ptr = p.value
+        ctx._buffers.add(self)   # freed with the context if still alive then (raw device memory is not ref-counted)
 
     def free(self):
         if self.ptr:
@@ -284,9 +286,14 @@ class Context:
         _check(lib().adac_ctx_create(device, stream, C.byref(h)), "adac_ctx_create")
         self._h = h.value
         self.device = device
+        self._buffers = weakref.WeakSet()
 
     def close(self):
+        """Layouts, plans and graphs made on the context keep it alive on the C side (reference counts); raw device
+        buffers do not, so the ones still alive are freed here."""
         if getattr(self, "_h", None):
+            for b in list(self._buffers):
+                b.free()
             lib().adac_ctx_destroy(self._h)
             self._h = None
 

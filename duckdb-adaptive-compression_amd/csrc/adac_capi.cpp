@@ -3,6 +3,7 @@
 // lives in adac_kernels.hip.  There is deliberately no CPU implementation behind any device entry point.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -35,7 +36,20 @@ struct adac_ctx {
 	hipStream_t stream = nullptr;
 	bool owns_stream = false;
 	hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+	// one reference for the creator + one per layout / plan / graph made on the context: objects may be destroyed
+	// in any order, the stream goes away with the last of them
+	std::atomic<int> refs {1};
 };
+
+static void ctx_retain(adac_ctx *c) { c->refs.fetch_add(1); }
+static void ctx_release(adac_ctx *c) {
+	if (c->refs.fetch_sub(1) != 1) return;
+	(void)hipSetDevice(c->device);
+	if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+	if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+	if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
+	delete c;
+}
 
 struct adac_layout {
 	adac_ctx *ctx = nullptr;
@@ -230,12 +244,7 @@ extern "C" adac_status adac_ctx_create(int device, void *external_stream, adac_c
 }
 
 extern "C" void adac_ctx_destroy(adac_ctx *c) {
-	if (!c) return;
-	(void)hipSetDevice(c->device);
-	if (c->ev_start) (void)hipEventDestroy(c->ev_start);
-	if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
-	if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
-	delete c;
+	if (c) ctx_release(c);
 }
 
 extern "C" adac_status adac_ctx_sync(adac_ctx *c) {
@@ -354,6 +363,7 @@ extern "C" adac_status adac_capture_end(adac_ctx *c, adac_graph **out) {
 		return ADAC_ERR_OUT_OF_MEMORY;
 	}
 	h->ctx = c;
+	ctx_retain(c);
 	h->graph = g;
 	h->exec = exec;
 	*out = h;
@@ -372,7 +382,9 @@ extern "C" void adac_graph_destroy(adac_graph *g) {
 	(void)hipSetDevice(g->ctx->device);
 	if (g->exec) (void)hipGraphExecDestroy(g->exec);
 	if (g->graph) (void)hipGraphDestroy(g->graph);
+	adac_ctx *c = g->ctx;
 	delete g;
+	ctx_release(c);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -388,6 +400,7 @@ extern "C" adac_status adac_layout_create(adac_ctx *c, int type, const uint32_t 
 	adac_layout *l = new (std::nothrow) adac_layout();
 	if (!l) return ADAC_ERR_OUT_OF_MEMORY;
 	l->ctx = c;
+	ctx_retain(c);
 	l->type = type;
 	l->type_size = adac_type_size(type);
 	l->is_signed = type_is_signed(type);
@@ -422,7 +435,7 @@ extern "C" adac_status adac_layout_create(adac_ctx *c, int type, const uint32_t 
 	l->max_arena_words = arena;
 	l->ntiles = tiles.size();
 	if (l->ntiles >= 0x7fffffffull) { // grid.x limit
-		delete l;
+		adac_layout_destroy(l);
 		return ADAC_ERR_INVALID_ARGUMENT;
 	}
 	hipError_t e = hipSetDevice(c->device);
@@ -455,7 +468,9 @@ extern "C" void adac_layout_destroy(adac_layout *l) {
 	if (l->d_block_tot) (void)hipFree(l->d_block_tot);
 	if (l->d_group_refs) (void)hipFree(l->d_group_refs);
 	if (l->d_groups) (void)hipFree(l->d_groups);
+	adac_ctx *c = l->ctx;
 	delete l;
+	ctx_release(c);
 }
 
 extern "C" uint64_t adac_layout_nseg(const adac_layout *l) { return l ? l->nseg : 0; }
@@ -800,6 +815,7 @@ extern "C" adac_status adac_bp_layout_create(adac_ctx *c, int physical_type, con
 	adac_bp_layout *l = new (std::nothrow) adac_bp_layout();
 	if (!l) return ADAC_ERR_OUT_OF_MEMORY;
 	l->ctx = c;
+	ctx_retain(c);
 	l->type_size = adac_type_size(physical_type);
 	l->nseg = nseg;
 	l->counts.assign(counts, counts + nseg);
@@ -807,7 +823,7 @@ extern "C" adac_status adac_bp_layout_create(adac_ctx *c, int physical_type, con
 	uint64_t run = 0;
 	for (uint64_t s = 0; s < nseg; s++) {
 		if (block_offs[s] & 15) {
-			delete l;
+			adac_bp_layout_destroy(l);
 			return ADAC_ERR_INVALID_ARGUMENT;
 		}
 		const uint64_t off = out_offs ? out_offs[s] : run;
@@ -820,7 +836,7 @@ extern "C" adac_status adac_bp_layout_create(adac_ctx *c, int physical_type, con
 	}
 	l->ngroups = groups.size();
 	if (l->ngroups >= 0x7fffffffull) {
-		delete l;
+		adac_bp_layout_destroy(l);
 		return ADAC_ERR_INVALID_ARGUMENT;
 	}
 	hipError_t e = hipSetDevice(c->device);
@@ -846,7 +862,9 @@ extern "C" void adac_bp_layout_destroy(adac_bp_layout *l) {
 	(void)hipSetDevice(l->ctx->device);
 	if (l->d_groups) (void)hipFree(l->d_groups);
 	if (l->d_block_offs) (void)hipFree(l->d_block_offs);
+	adac_ctx *c = l->ctx;
 	delete l;
+	ctx_release(c);
 }
 
 extern "C" uint64_t adac_bp_layout_ngroups(const adac_bp_layout *l) { return l ? l->ngroups : 0; }
@@ -972,7 +990,9 @@ extern "C" void adac_bp_plan_destroy(adac_bp_plan *p) {
 	if (!p) return;
 	(void)hipSetDevice(p->ctx->device);
 	if (p->d_recs) (void)hipFree(p->d_recs);
+	adac_ctx *c = p->ctx;
 	delete p;
+	ctx_release(c);
 }
 
 extern "C" adac_status adac_bp_plan_create(adac_ctx *c, int physical_type, const void *d_vals, const uint64_t *d_validity,
@@ -983,6 +1003,7 @@ extern "C" adac_status adac_bp_plan_create(adac_ctx *c, int physical_type, const
 	adac_bp_plan *p = new (std::nothrow) adac_bp_plan();
 	if (!p) return ADAC_ERR_OUT_OF_MEMORY;
 	p->ctx = c;
+	ctx_retain(c);
 	p->type_size = adac_type_size(physical_type);
 	p->is_signed = type_is_signed(physical_type);
 	p->n = n;

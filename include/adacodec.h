@@ -140,6 +140,9 @@ int adac_set_tuning(const char *name, int value);
 /* Binds to HIP device `device`.  external_stream: a hipStream_t owned by the caller (e.g. the engine's or
  * torch's current stream) or NULL to create a private non-blocking stream. */
 adac_status adac_ctx_create(int device, void *external_stream, adac_ctx **out);
+/* Layouts, plans and graphs hold a reference on their context: adac_ctx_destroy drops the creator's reference and
+ * the stream goes away with the last object made on it, so destruction order does not matter.  Raw device memory
+ * (adac_dev_alloc) is not tracked: free it before the context. */
 void adac_ctx_destroy(adac_ctx *ctx);
 adac_status adac_ctx_sync(adac_ctx *ctx);
 void *adac_ctx_stream(adac_ctx *ctx); /* the hipStream_t every launch of this ctx goes to */

@@ -538,3 +538,31 @@ def test_scans_on_segments_crossing_the_sign_boundary(adac, oracle, gpu_ctx):
                     assert d_res.download(np.uint64, len(counts)).tolist() == exp, (dtype, templated, a, b)
         finally:
             adac.set_tuning("templated_scan", 1)
+
+
+def test_objects_outlive_their_context_safely(adac, oracle):
+    """Contexts are reference-counted by the layouts / plans / graphs made on them: destroying the context first
+    (and creating the next one right away) must leave everything usable and leak-free in any order."""
+    ctx = adac.Context(0)
+    vals = np.arange(100_000, dtype=np.uint32)
+    counts = adac.appender_segment_counts(len(vals), 4)
+    lay = adac.Layout(ctx, np.uint32, counts)
+    d_vals = ctx.upload(vals)
+    d_words = ctx.alloc(lay.max_arena_words * 8 + 16).zero()
+    lay.encode(d_vals, d_words)
+    d_sum = ctx.alloc(len(counts) * 8)
+    lay.scan_sum(d_words, d_sum)
+    ctx.sync()
+    assert int(d_sum.download(np.uint64, len(counts)).sum()) == int(vals.astype(np.uint64).sum())
+    ctx.close()                     # the layout is still alive: it keeps the C context, buffers are freed here
+    ctx2 = adac.Context(0)
+    lay2 = adac.Layout(ctx2, np.uint32, counts)      # used to fail when a dangling context was touched before
+    d2 = ctx2.upload(vals)
+    w2 = ctx2.alloc(lay2.max_arena_words * 8 + 16).zero()
+    lay2.encode(d2, w2)
+    out = ctx2.alloc(len(vals) * 4 + 16)
+    lay2.unpack(w2, out)
+    assert np.array_equal(out.download(np.uint32, len(vals)), vals)
+    lay.close()                     # last reference of the first context
+    del lay2
+    ctx2.close()
