@@ -272,13 +272,13 @@ __global__ __launch_bounds__(kWorkgroup) void k_unpack(const adac_segment_desc *
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_scan_sum / k_scan_count_eq — fused scan + aggregate, nothing materialised.
+// k_scan_agg — fused scans (SUM, COUNT(range), selection bitmap), nothing materialised.
 // ---------------------------------------------------------------------------------------------
-// Fused scans are sized by PACKED BYTES, not rows: a workgroup owns `group` consecutive tile-table entries and
-// stages as many whole tiles of one segment as fit the 16 KiB LDS image at that segment's width (8 tiles of
-// u64 at w <= 8, 2 at w = 32, ...), so ~16 KiB of HBM reads are in flight per workgroup at every width — at
-// one 2 KiB tile per stage (w = 8) a CU has too few bytes in flight to cover HBM latency.  The aggregate is
-// carried in registers across stages and flushed (wave reduce + one atomic per wave) once per segment run.
+// LDS form (widths the register path does not take: w < 4, w > 32, segments whose fields are not their values):
+// a workgroup owns one ScanGroup work item — several tiles of ONE segment — and stages as many whole tiles as
+// fit the 16 KiB LDS image at that segment's width (8 tiles of u64 at w <= 8, 2 at w = 32, ...), so ~16 KiB of
+// HBM reads are in flight per workgroup at every width.  The aggregate is carried in registers across stages
+// and flushed (wave reduce + one atomic per wave) once per work item.
 template <typename U, bool WIDE, typename Sink>
 __device__ __forceinline__ void decode_run(const uint32_t *lds32, uint32_t bit0, uint32_t w, uint64_t add, uint32_t n,
                                            Sink &&sink) {
