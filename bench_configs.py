@@ -254,7 +254,8 @@ def q6_packed(adac, n=59_986_052):
     out = {"rows": n, "selected_rows": int(m.sum()), "widths": {k: v[2] for k, v in enc.items()},
            "packed_bytes": packed_bytes, "q6_on_packed_ms": ms, "q6_as_hip_graph_ms": ms_graph, "q6_rows_per_s": n / (ms * 1e-3),
            "q6_packed_read_GBps": packed_bytes / (ms * 1e-3) / 1e9,
-           "decode_four_columns_ms": ms_dec, "q6_ms_by_scan_tiles_per_wg": by_group, "step_ms": steps,
+           "decode_four_columns_ms": ms_dec,
+           "decode_four_columns_total_GBps": (packed_bytes + 4 * n * 4) / (ms_dec * 1e-3) / 1e9, "q6_ms_by_scan_tiles_per_wg": by_group, "step_ms": steps,
            "note": "q6_on_packed = 3 chained filter scans (selection bitmaps) + 1 masked SUM; decode_four_columns is "
                    "only the materialisation a decode-then-filter plan would pay before filtering"}
     ctx.close()
