@@ -144,6 +144,7 @@ SIGNATURES = {
     "adac_bp_layout_total_values": (_u64, [_vp]),
     "adac_bp_bind": (_int, [_vp, _vp]),
     "adac_bp_unpack": (_int, [_vp, _vp, _vp]),
+    "adac_bp_unpack_range": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _u64]),
     "adac_bp_fetch_rows": (_int, [_vp, _vp, _vp, _vp, _u64, _vp]),
     "adac_bp_plan_create": (_int, [_vp, _int, _vp, _vp, _u64, _int, _P(_vp)]),
     "adac_bp_plan_destroy": (None, [_vp]),
@@ -506,6 +507,10 @@ class BitpackingLayout:
 
     def unpack(self, d_blocks, d_out):
         _check(lib().adac_bp_unpack(self._h, _dptr(d_blocks), _dptr(d_out)), "adac_bp_unpack")
+
+    def unpack_range(self, d_blocks, seg, start, count, d_out, out_off=0):
+        _check(lib().adac_bp_unpack_range(self._h, _dptr(d_blocks), seg, start, count, _dptr(d_out), out_off),
+               "adac_bp_unpack_range")
 
     def fetch_rows(self, d_blocks, d_segs, d_rows, n, d_out):
         _check(lib().adac_bp_fetch_rows(self._h, _dptr(d_blocks), _dptr(d_segs), _dptr(d_rows), n, _dptr(d_out)),

@@ -127,7 +127,7 @@ struct BpScan {
 template <typename U, bool WIDE>
 __device__ __forceinline__ void bp_delta_scan(const uint32_t *lds32, uint32_t bit0, uint32_t w, uint64_t frame,
                                               U delta_offset, uint32_t n, uint32_t align, U *__restrict__ dst,
-                                              U (*wave_tot)[kWorkgroup / 64]) {
+                                              uint32_t store_from, U (*wave_tot)[kWorkgroup / 64]) {
 	constexpr int K = BpScan<U>::K;
 	constexpr int ROUNDS = BpScan<U>::ROUNDS;
 	constexpr int WAVES = kWorkgroup / 64;
@@ -169,44 +169,68 @@ __device__ __forceinline__ void bp_delta_scan(const uint32_t *lds32, uint32_t bi
 		const int32_t base = (int32_t)((r * kWorkgroup + threadIdx.x) * K) - (int32_t)align;
 #pragma unroll
 		for (int j = 0; j < K; j++) v[r][j] = (U)(v[r][j] + before);
-		if (base >= 0 && (uint32_t)(base + K) <= n) {
+		// dst is the (possibly virtual) address of row 0; only rows in [store_from, n) are written
+		if (base >= (int32_t)store_from && (uint32_t)(base + K) <= n) {
 			uint4 q;
 			__builtin_memcpy(&q, v[r], 16);
 			*reinterpret_cast<uint4 *>(dst + base) = q;
 		} else {
 #pragma unroll
 			for (int j = 0; j < K; j++) {
-				if ((uint32_t)(base + j) < n) dst[base + j] = v[r][j];
+				const uint32_t row = (uint32_t)(base + j);
+				if (row < n && row >= store_from) dst[base + j] = v[r][j];
 			}
 		}
 	}
 }
 
-template <typename U>
+// Range form (BitpackingScanPartial with an arbitrary start, bitpacking.cpp:736-826): rows
+// [start, start + count) of ONE segment, written to out[out_off ...].  group0 is the index of the metadata group
+// holding `start` in the layout's group table, skip_first the row of `start` inside it.
+struct BpRangeArgs {
+	uint32_t group0;
+	uint32_t skip_first;
+	uint64_t count;
+	uint64_t out_off;
+};
+
+template <typename U, bool RANGE>
 __global__ __launch_bounds__(kWorkgroup) void k_bp_unpack(const BpGroup *__restrict__ groups,
-                                                          const uint8_t *__restrict__ blocks, U *__restrict__ out) {
+                                                          const uint8_t *__restrict__ blocks, BpRangeArgs range,
+                                                          U *__restrict__ out) {
 	__shared__ uint4 lds[kTileBytes / 16 + 2];
 	__shared__ U wave_tot[BpScan<U>::ROUNDS][kWorkgroup / 64];
-	const BpGroup g = groups[blockIdx.x];
+	const BpGroup g = groups[(RANGE ? range.group0 : 0u) + blockIdx.x];
 	BpHeader h;
 	h.mode = g.mode;
 	h.width = g.width;
 	h.frame = g.frame;
 	h.extra = g.extra;
 	h.payload = blocks + g.payload_off;
-	U *dst = out + g.out_off;
-	const uint32_t n = g.rows;
 	constexpr uint32_t K = 16 / sizeof(U);
-	const uint32_t align = (uint32_t)(g.out_off & (K - 1));
+	// rows [a, n) of the group are wanted; row r lands at out[shift + r].  (For DELTA_FOR rows below a are still
+	// decoded: they are part of the prefix.)
+	uint32_t a = 0, n = g.rows;
+	int64_t shift = (int64_t)g.out_off;
+	if (RANGE) {
+		a = blockIdx.x == 0 ? range.skip_first : 0u;
+		const uint64_t pos = (uint64_t)blockIdx.x * kBpGroupRows + a - range.skip_first; // of row a in the range
+		if (pos >= range.count || a >= n) return;
+		const uint64_t want = range.count - pos;
+		if (want < (uint64_t)(n - a)) n = a + (uint32_t)want;
+		shift = (int64_t)(range.out_off + pos) - (int64_t)a;
+	}
+	U *dst = out + shift; // address of row 0 of the group (virtual when a > 0: only rows >= a are touched)
+	const uint32_t align = (uint32_t)((shift + (int64_t)a) & (int64_t)(K - 1)); // of the first stored row
 
 	if (h.mode == kBpConstant || h.mode == kBpConstantDelta || h.width == 0) {
 		// CONSTANT: fill; CONSTANT_DELTA: i*delta + for (bitpacking.cpp:759-780); width 0: every field is zero
 		const U fr = (U)h.frame;
 		const U step = h.mode == kBpConstantDelta ? (U)h.extra : (U)0;
 		if (h.mode == kBpDeltaFor) { // zero-width deltas: v[i] = delta_offset + (i+1)*for
-			for (uint32_t i = threadIdx.x; i < n; i += kWorkgroup) dst[i] = (U)((U)h.extra + (U)(i + 1) * fr);
+			for (uint32_t i = a + threadIdx.x; i < n; i += kWorkgroup) dst[i] = (U)((U)h.extra + (U)(i + 1) * fr);
 		} else {
-			for (uint32_t i = threadIdx.x; i < n; i += kWorkgroup) dst[i] = (U)((U)i * step + fr);
+			for (uint32_t i = a + threadIdx.x; i < n; i += kWorkgroup) dst[i] = (U)((U)i * step + fr);
 		}
 		return;
 	}
@@ -222,23 +246,24 @@ __global__ __launch_bounds__(kWorkgroup) void k_bp_unpack(const BpGroup *__restr
 	const uint32_t *lds32 = reinterpret_cast<const uint32_t *>(lds);
 
 	if (h.mode == kBpFor) {
-		StoreSink<U> sink {dst, n}; // value = field + frame_of_reference (ApplyFrameOfReference)
+		StoreSink<U> sink {dst + a, n - a}; // value = field + frame_of_reference (ApplyFrameOfReference)
 		if (sizeof(U) == 8 && w > 32) {
-			decode_rows<U, true>(lds32, bit0, w, h.frame, n, align, sink);
+			decode_rows<U, true>(lds32, bit0 + a * w, w, h.frame, n - a, align, sink);
 		} else {
-			decode_rows<U, false>(lds32, bit0, w, h.frame, n, align, sink);
+			decode_rows<U, false>(lds32, bit0 + a * w, w, h.frame, n - a, align, sink);
 		}
 		return;
 	}
 
 	// DELTA_FOR: v[i] = delta_offset + sum_{j<=i} (field[j] + for), wrapping in T (bitpacking.cpp:810-813).
 	// A lane decodes the K consecutive rows of one 16-byte output chunk into registers and scans them; lanes are
-	// chained by a wave64 shuffle scan, waves by four totals through LDS (double-buffered: one barrier per round of
-	// 256 chunks), rounds by a running carry.  The values never visit LDS and leave with 16-byte stores.
+	// chained by a DPP wave64 prefix sum, waves by four totals through LDS, and every round of 256 chunks is
+	// decoded and scanned before the single barrier.  The values never visit LDS and leave with 16-byte stores.
+	const uint32_t scan_align = (uint32_t)(shift & (int64_t)(K - 1)); // chunks are aligned on row 0's address
 	if (sizeof(U) == 8 && w > 32) {
-		bp_delta_scan<U, true>(lds32, bit0, w, h.frame, (U)h.extra, n, align, dst, wave_tot);
+		bp_delta_scan<U, true>(lds32, bit0, w, h.frame, (U)h.extra, n, scan_align, dst, a, wave_tot);
 	} else {
-		bp_delta_scan<U, false>(lds32, bit0, w, h.frame, (U)h.extra, n, align, dst, wave_tot);
+		bp_delta_scan<U, false>(lds32, bit0, w, h.frame, (U)h.extra, n, scan_align, dst, a, wave_tot);
 	}
 }
 

@@ -801,6 +801,7 @@ struct adac_bp_layout {
 	uint32_t type_size = 0;
 	uint64_t nseg = 0, ngroups = 0, total_values = 0;
 	std::vector<uint32_t> counts;
+	std::vector<uint64_t> seg_first_group; // index of each segment's first metadata group in the group table
 	void *d_groups = nullptr;
 	uint64_t *d_block_offs = nullptr;
 	const void *bound_blocks = nullptr; // blocks buffer whose group headers are parsed into d_groups
@@ -827,6 +828,7 @@ extern "C" adac_status adac_bp_layout_create(adac_ctx *c, int physical_type, con
 			return ADAC_ERR_INVALID_ARGUMENT;
 		}
 		const uint64_t off = out_offs ? out_offs[s] : run;
+		l->seg_first_group.push_back(groups.size());
 		for (uint64_t r = 0; r < counts[s]; r += 2048) {
 			const uint32_t rows = (uint32_t)(counts[s] - r < 2048 ? counts[s] - r : 2048);
 			groups.push_back(adac::BpGroupHost {block_offs[s], off + r, (uint32_t)(r / 2048), rows, 0, 0, 0, 0, 0});
@@ -887,6 +889,23 @@ extern "C" adac_status adac_bp_unpack(adac_bp_layout *l, const void *d_blocks, v
 	}
 	ADAC_HIP(hipSetDevice(l->ctx->device));
 	ADAC_HIP(adac::launch_bp_unpack(l->ctx->stream, l->type_size, l->d_groups, l->ngroups, d_blocks, d_out));
+	return ADAC_OK;
+}
+
+extern "C" adac_status adac_bp_unpack_range(adac_bp_layout *l, const void *d_blocks, uint64_t seg, uint64_t start,
+                                            uint64_t count, void *d_out, uint64_t out_off) {
+	if (!l || seg >= l->nseg) return ADAC_ERR_INVALID_ARGUMENT;
+	if (start > l->counts[seg] || count > l->counts[seg] - start) return ADAC_ERR_INVALID_ARGUMENT;
+	if (count == 0) return ADAC_OK;
+	if (!d_blocks || !d_out || !aligned16(d_blocks) || !aligned16(d_out)) return ADAC_ERR_INVALID_ARGUMENT;
+	if (l->bound_blocks != d_blocks) {
+		adac_status st = adac_bp_bind(l, d_blocks);
+		if (st != ADAC_OK) return st;
+	}
+	ADAC_HIP(hipSetDevice(l->ctx->device));
+	const uint64_t g0 = l->seg_first_group[seg] + start / 2048;
+	ADAC_HIP(adac::launch_bp_unpack_range(l->ctx->stream, l->type_size, l->d_groups, (uint32_t)g0,
+	                                      (uint32_t)(start % 2048), count, out_off, d_blocks, d_out));
 	return ADAC_OK;
 }
 

@@ -122,6 +122,9 @@ hipError_t launch_bp_write(hipStream_t s, uint32_t type_size, const void *d_recs
 hipError_t launch_bp_prepare(hipStream_t s, uint32_t type_size, void *d_groups, uint64_t ngroups, const void *d_blocks);
 hipError_t launch_bp_unpack(hipStream_t s, uint32_t type_size, const void *d_groups, uint64_t ngroups,
                             const void *d_blocks, void *d_out);
+hipError_t launch_bp_unpack_range(hipStream_t s, uint32_t type_size, const void *d_groups, uint32_t group0,
+                                  uint32_t skip_first, uint64_t count, uint64_t out_off, const void *d_blocks,
+                                  void *d_out);
 hipError_t launch_bp_fetch(hipStream_t s, uint32_t type_size, const uint64_t *d_block_offs, const void *d_blocks,
                            const uint32_t *d_segs, const uint32_t *d_rows, uint64_t n, void *d_out);
 

@@ -1478,9 +1478,23 @@ hipError_t launch_bp_unpack(hipStream_t s, uint32_t type_size, const void *d_gro
 	if (ngroups == 0) return hipSuccess;
 	return dispatch_size(type_size, [&](auto tag) {
 		using U = decltype(tag);
-		hipLaunchKernelGGL(k_bp_unpack<U>, dim3((unsigned)ngroups), dim3(kWorkgroup), 0, s,
-		                   static_cast<const BpGroup *>(d_groups), static_cast<const uint8_t *>(d_blocks),
+		hipLaunchKernelGGL((k_bp_unpack<U, false>), dim3((unsigned)ngroups), dim3(kWorkgroup), 0, s,
+		                   static_cast<const BpGroup *>(d_groups), static_cast<const uint8_t *>(d_blocks), BpRangeArgs {},
 		                   static_cast<U *>(d_out));
+		return hipGetLastError();
+	});
+}
+
+hipError_t launch_bp_unpack_range(hipStream_t s, uint32_t type_size, const void *d_groups, uint32_t group0,
+                                  uint32_t skip_first, uint64_t count, uint64_t out_off, const void *d_blocks,
+                                  void *d_out) {
+	if (count == 0) return hipSuccess;
+	return dispatch_size(type_size, [&](auto tag) {
+		using U = decltype(tag);
+		const uint64_t ngroups = ((uint64_t)skip_first + count + kBpGroupRows - 1) / kBpGroupRows;
+		hipLaunchKernelGGL((k_bp_unpack<U, true>), dim3((unsigned)ngroups), dim3(kWorkgroup), 0, s,
+		                   static_cast<const BpGroup *>(d_groups), static_cast<const uint8_t *>(d_blocks),
+		                   BpRangeArgs {group0, skip_first, count, out_off}, static_cast<U *>(d_out));
 		return hipGetLastError();
 	});
 }

@@ -331,6 +331,12 @@ uint64_t adac_bp_layout_total_values(const adac_bp_layout *l);
 adac_status adac_bp_bind(adac_bp_layout *l, const void *d_blocks);
 /* Full scan: every row of every segment to d_out (16-byte aligned), one workgroup per 2048-row metadata group. */
 adac_status adac_bp_unpack(adac_bp_layout *l, const void *d_blocks, void *d_out);
+/* Rows [start, start + count) of segment `seg` into d_out[out_off ...] — BitpackingScanPartial / BitpackingScan
+ * (bitpacking.cpp:736-826) for any start: a DELTA_FOR group that the range enters in the middle is prefix-summed
+ * from its first row, as the reference's Skip + LoadNextGroup do. */
+adac_status adac_bp_unpack_range(adac_bp_layout *l, const void *d_blocks, uint64_t seg, uint64_t start, uint64_t count,
+                                 void *d_out, uint64_t out_off);
+
 /* d_out[k] = row d_rows[k] of segment d_segs[k] */
 adac_status adac_bp_fetch_rows(adac_bp_layout *l, const void *d_blocks, const uint32_t *d_segs, const uint32_t *d_rows,
                                uint64_t n, void *d_out);

@@ -226,3 +226,39 @@ def test_gpu_compress_forced_modes_nulls_and_many_segments(adac, gpu_ctx):
     assert not plan.encodable and d_blocks is None and plan.nseg == 0
     with pytest.raises(ValueError):
         bp.Compressed(bad)
+
+
+@pytest.mark.parametrize("dtype", ALL)
+def test_range_scans_from_any_start(adac, gpu_ctx, dtype):
+    """adac_bp_unpack_range = BitpackingScanPartial for arbitrary (start, count): ranges that begin and end inside
+    groups of every mode (a DELTA_FOR group entered in the middle still needs its prefix), single rows, whole
+    segments, unaligned output offsets — against the oracle's scan of the same block."""
+    dtype = np.dtype(dtype)
+    rng = np.random.default_rng(400 + dtype.itemsize + (dtype.kind == "i"))
+    v = mixed_column(dtype, rng, groups=11)
+    comp = bp.Compressed(v)
+    d_blocks, offs, counts = upload_blocks(gpu_ctx, comp)
+    lay = adac.BitpackingLayout(gpu_ctx, dtype, offs, counts)
+    row0 = 0
+    for seg in range(comp.nseg):
+        c = int(counts[seg])
+        cases = [(0, c), (0, 1), (c - 1, 1), (2047, 2), (2048, 2048), (1, c - 1)]
+        for _ in range(12):
+            s = int(rng.integers(0, c))
+            cases.append((s, int(rng.integers(1, c - s + 1))))
+        for start, cnt in cases:
+            if start + cnt > c:
+                continue
+            shift = int(rng.integers(0, 9))
+            d_out = gpu_ctx.alloc((cnt + shift) * dtype.itemsize + 64)
+            d_out.upload(np.full(cnt + shift + 8, 0x5A, dtype=np.uint8).repeat(dtype.itemsize).view(dtype)[:cnt + shift])
+            lay.unpack_range(d_blocks, seg, start, cnt, d_out, shift)
+            got = d_out.download(dtype, cnt + shift)
+            exp = comp.scan(seg, start, cnt)
+            assert np.array_equal(got[shift:], exp), (dtype.name, seg, start, cnt, shift)
+            assert np.array_equal(exp, v[row0 + start:row0 + start + cnt])
+            if shift:
+                assert (got[:shift].view(np.uint8) == 0x5A).all()      # nothing before the range is touched
+        row0 += c
+    with pytest.raises(adac.AdacError):
+        lay.unpack_range(d_blocks, 0, int(counts[0]), 1, d_out)       # past the segment
