@@ -83,6 +83,7 @@ SIGNATURES = {
     "adac_type_size": (_u32, [_int]),
     "adac_hi": (_u32, [_u64]),
     "adac_width": (_u8, [_u64, _u64, _int, _int]),
+    "adac_stored_min": (_u64, [_u64, _u64, _u8]),
     "adac_packed_words": (_u64, [_u64, _u8]),
     "adac_size_in_bytes": (_u64, [_u64, _u8]),
     "adac_arena_words": (_u64, [_u64, _u8]),
@@ -190,6 +191,11 @@ def _dptr(x):
 
 
 # host-only helpers -------------------------------------------------------------------------------
+
+def stored_min(mn, mx, w):
+    """The min a PACKED descriptor stores (differs from mn only for the all-ones sentinel collision)."""
+    return lib().adac_stored_min(mn & NO_MIN, mx & NO_MIN, w)
+
 
 def width(mn, mx, rule=RULE_APPEND, pad_to_byte=False):
     return lib().adac_width(mn & NO_MIN, mx & NO_MIN, rule, int(pad_to_byte))

@@ -130,6 +130,12 @@ extern "C" uint8_t adac_width(uint64_t mn, uint64_t mx, int rule, int pad_to_byt
 	return (uint8_t)w;
 }
 
+extern "C" uint64_t adac_stored_min(uint64_t min, uint64_t max, uint8_t width) {
+	// see k_plan: the all-ones segment keeps the reference's packed bits but gets a min that decodes them
+	if (min == UINT64_MAX && max == UINT64_MAX && width >= 1 && width < 64) return UINT64_MAX - ((1ull << width) - 1ull);
+	return min;
+}
+
 extern "C" uint64_t adac_packed_words(uint64_t count, uint8_t width) { return (count * width + 63) >> 6; }
 
 extern "C" uint64_t adac_size_in_bytes(uint64_t count, uint8_t width) { return 9 + (adac_packed_words(count, width) << 3); }

@@ -1014,6 +1014,12 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan(adac_segment_desc *__rest
 			if (type_bits > cand) { // `if (old_width > min_width)` column_segment.cpp:363,420
 				w = cand;
 				flags = ADAC_SEG_PACKED;
+				// Sentinel collision (reference defect 7): min == max == UINT64_MAX means every valid row is
+				// all-ones (-1 for the INT types), but UINT64_MAX is also "no min": the reference then packs
+				// WITHOUT subtracting (column_segment.cpp:371-373) and scans without adding (succinct.cpp:138-140),
+				// returning 2^w - 1 instead of -1.  Storing min = UINT64_MAX - (2^w - 1) keeps the packed bits
+				// identical (x - min' = 2^w - 1 = x mod 2^w) and makes field + min' the original value.
+				if (mn == ~0ull && mx == ~0ull) mn = ~0ull - mask64(w);
 			}
 			const uint64_t bits = (uint64_t)descs[s].count * w;
 			fp = (((bits + 64) >> 6) + 15) & ~15ull; // SDSL allocation, rounded to 128 B

@@ -657,7 +657,7 @@ void ColumnSegment::CompactMany(DatabaseInstance &db, const std::vector<ColumnSe
 				adac_segment_desc d;
 				d.word_off = db.pool.Allocate(adac_arena_words(counts[i], w));
 				d.val_off = offs[i];
-				d.min = mm[2 * i];
+				d.min = adac_stored_min(mm[2 * i], mm[2 * i + 1], w); // all-ones segments: see adacodec.h
 				d.count = counts[i];
 				d.width = w;
 				d.flags = ADAC_SEG_PACKED;

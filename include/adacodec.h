@@ -97,6 +97,14 @@ uint32_t adac_hi(uint64_t x);
 /* Minimal width for a segment: column_segment.cpp:351-359 (rule APPEND) / :404-417 (rule RECOMPACT);
  * pad_to_byte = DBConfig::succinct_padded_to_next_byte_enabled (config.hpp:193). */
 uint8_t adac_width(uint64_t min, uint64_t max, int rule, int pad_to_byte);
+/* The min a PACKED descriptor stores for a segment analysed to (min, max) and planned at `width`: min itself,
+ * except for the sentinel collision min == max == UINT64_MAX (every valid row is all-ones, -1 for the INT types):
+ * the reference packs such a segment without subtracting and scans it without adding (UINT64_MAX doubles as "no
+ * min": column_segment.cpp:371-373, succinct.cpp:138-140), returning 2^width - 1 instead of -1.  The product
+ * keeps those packed bits and stores min = UINT64_MAX - (2^width - 1), which decodes them to the original value.
+ * adac_plan applies this on the device; hosts that build descriptors themselves (adac_layout_set_descs) call it. */
+uint64_t adac_stored_min(uint64_t min, uint64_t max, uint8_t width);
+
 /* ceil(count*width/64): logical uint64 words of a packed segment (int_vector::capacity()/64) */
 uint64_t adac_packed_words(uint64_t count, uint8_t width);
 /* sdsl::size_in_bytes(succinct_vec) = 9 + 8*ceil(count*width/64) (io.hpp:636-640,

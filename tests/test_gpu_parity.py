@@ -76,7 +76,7 @@ def run_encode_decode(adac, orc, ctx, dtype, counts, seg_vals, rule=0, padded=Fa
         assert bool(d["flags"] & adac.SEG_PACKED) == packed
         assert int(d["word_off"]) == woff and woff % 16 == 0
         if packed:
-            assert int(d["min"]) == mn
+            assert int(d["min"]) == adac.stored_min(mn, mx, w)   # mn, except for the all-ones sentinel collision
         got = words_all[woff:woff + len(words)]
         assert np.array_equal(got, words), "packed words of segment %d (w=%d)" % (s, w)
         assert adac.size_in_bytes(len(seg_vals[s]), w) == orc.size_in_bytes(len(seg_vals[s]) * w)
@@ -91,7 +91,8 @@ def run_encode_decode(adac, orc, ctx, dtype, counts, seg_vals, rule=0, padded=Fa
     for s, (mn, mx, w, packed, words) in enumerate(exp):
         o = int(offs[s])
         n = len(seg_vals[s])
-        add = mn if (packed and mn != U64) else 0
+        smin = adac.stored_min(mn, mx, w) if packed else mn
+        add = smin if (packed and smin != U64) else 0
         ref = orc.unpack_flat(words, 0, n, w, add, dtype)
         assert np.array_equal(out[o:o + n], ref), "decode of segment %d (w=%d)" % (s, w)
         if validity is None:
@@ -566,3 +567,38 @@ def test_objects_outlive_their_context_safely(adac, oracle):
     lay.close()                     # last reference of the first context
     del lay2
     ctx2.close()
+
+
+@pytest.mark.parametrize("dtype", [np.int8, np.int16, np.int32, np.int64, np.uint64])
+def test_all_ones_segment_survives_the_sentinel_collision(adac, oracle, gpu_ctx, dtype):
+    """Reference defect 7: a segment whose every value is -1 (all ones) has min == max == UINT64_MAX, which the
+    reference also uses for "no min": it packs without subtracting and scans without adding, returning 2^w - 1
+    (1, or 255 when padded) instead of -1.  The product keeps those packed bits and decodes the original value,
+    in the decode, the fused scans and the point fetch."""
+    dtype = np.dtype(dtype)
+    ones = np.array([-1 if dtype.kind == "i" else np.iinfo(dtype).max], dtype=dtype)[0]
+    rng = np.random.default_rng(3)
+    segs = [np.full(5000, ones, dtype=dtype), make_values(rng, dtype, 3000, 5), np.full(1, ones, dtype=dtype),
+            np.full(70000, ones, dtype=dtype)]
+    counts = np.array([len(v) for v in segs], dtype=np.uint32)
+    for padded in (False, True):
+        lay, d_words, d_out, descs, out = run_encode_decode(adac, oracle, gpu_ctx, dtype, counts, segs,
+                                                            adac.RULE_APPEND, padded)
+        w = 8 if padded else 1
+        if w < 8 * dtype.itemsize:   # (int8 padded to 8 bits does not shrink: it stays unpacked)
+            for s in (0, 2, 3):
+                assert int(descs["width"][s]) == w and descs["flags"][s] & adac.SEG_PACKED
+                assert int(descs["min"][s]) == 0xFFFFFFFFFFFFFFFF - ((1 << w) - 1)
+            # the reference's own reading of the same bits (oracle, reference mode): 2^w - 1, not the value
+            words0 = d_words.download(np.uint64, int(descs["word_off"][1]))
+            assert int(oracle.unpack_flat(words0, 0, 1, w, 0, np.uint64)[0]) == (1 << w) - 1
+        d_res = gpu_ctx.alloc(len(counts) * 8)
+        lay.scan_sum(d_words, d_res)
+        assert d_res.download(np.uint64, len(counts)).tolist() == [wide_sum(v) for v in segs]
+        key = int(np.array([ones]).view(np.dtype("u%d" % dtype.itemsize))[0])
+        lay.scan_count_eq(d_words, key, d_res)
+        assert d_res.download(np.uint64, len(counts)).tolist() == [int((v == ones).sum()) for v in segs]
+        d_f = gpu_ctx.alloc(8 * dtype.itemsize)
+        lay.fetch_rows(d_words, gpu_ctx.upload(np.array([0, 3, 2], dtype=np.uint32)),
+                       gpu_ctx.upload(np.array([4999, 69999, 0], dtype=np.uint32)), 3, d_f)
+        assert d_f.download(dtype, 3).tolist() == [ones] * 3
