@@ -349,6 +349,9 @@ ORC_API void orc_seg_uncompact(orc_segment *s, int correct) {
 		uint64_t c = ivec_get(&s->vec, i);
 		if (correct) {
 			if (packed && s->min_factor != UINT64_MAX) c += s->min_factor;
+			if (packed && s->min_factor == UINT64_MAX && s->max_factor == UINT64_MAX) { /* defect 7: adac_stored_min */
+				c += UINT64_MAX - ((1ull << s->vec.width) - 1ull);
+			}
 		} else {
 			c += s->min_factor;
 		}
@@ -433,9 +436,14 @@ ORC_API void orc_seg_scan_partial(const orc_segment *s, uint64_t start, uint64_t
 		add = s->min_factor != UINT64_MAX && src->width < ts * 8;
 	}
 	uint64_t mn = s->min_factor;
+	/* product semantics, defect 7 (sentinel collision): a packed segment with min == max == UINT64_MAX holds
+	 * only all-ones VALID values, stored as their unsubtracted low bits; the product decodes field + (UINT64_MAX -
+	 * (2^w - 1)) (adac_stored_min), the reference returns the field */
+	int all_ones = mode == 0 && src->width < ts * 8 && s->min_factor == UINT64_MAX && s->max_factor == UINT64_MAX;
 	for (uint64_t i = 0; i < n; i++) {
 		uint64_t e = ivec_get(src, start + i);
 		if (add) e += mn;
+		if (all_ones) e += UINT64_MAX - ((src->width >= 64 ? 0ull : (1ull << src->width)) - 1ull); /* adac_stored_min */
 		memcpy(dst + i * ts, &e, ts);
 	}
 	if (with_copy) free(tmp.data);
