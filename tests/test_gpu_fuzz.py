@@ -105,6 +105,26 @@ def test_random_columns(adac, oracle, gpu_ctx, seed):
     finally:
         adac.set_tuning("templated_scan", 1)
         adac.set_tuning("scan_tiles_per_wg", 0)
+    # scan with selection: the last bitmap's rows, values and element ids, dense and in row order
+    lo, hi = probes[-1]
+    expb = expected_bitmap(dec, [int(o) for o in offs], span, lo, hi, valid)
+    nsel = int(expb.sum())
+    d_sel = gpu_ctx.alloc(max(nsel, 1) * dtype.itemsize + 64)
+    d_ids = gpu_ctx.alloc(max(nsel, 1) * 8 + 64)
+    assert lay.unpack_selected(d_words, d_bm, d_sel, d_ids) == nsel
+    ids = np.flatnonzero(expb)
+    assert np.array_equal(d_ids.download(np.uint64, max(nsel, 1))[:nsel], ids.astype(np.uint64))
+    flat = np.zeros(span, dtype=dtype)
+    for v, o in zip(dec, offs):
+        flat[int(o):int(o) + len(v)] = v
+    assert np.array_equal(d_sel.download(dtype, max(nsel, 1))[:nsel], flat[ids])
+    # typed zonemaps of the raw values (valid rows only)
+    d_raw = gpu_ctx.upload(flat if span else np.zeros(1, dtype))
+    zm = lay.zonemap(d_raw, d_valid)
+    for s in nz:
+        v = dec[s] if valid is None else dec[s][valid[int(offs[s]):int(offs[s]) + len(dec[s])]]
+        if len(v):
+            assert (int(zm[s, 0]), int(zm[s, 1])) == (int(v.min()), int(v.max())), ("zonemap", s)
     # packed -> packed with the other padding choice: identical to a direct encode of what the column decodes to
     dst = adac.Layout(gpu_ctx, dtype, counts, offs)
     d_dst = gpu_ctx.alloc(dst.max_arena_words * 8 + 16).zero()
