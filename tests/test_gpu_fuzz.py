@@ -21,9 +21,10 @@ def random_case(rng, adac):
     nseg = int(rng.integers(1, 9))
     counts, segs = [], []
     for _ in range(nseg):
-        kind = int(rng.integers(0, 8))
+        kind = int(rng.integers(0, 9))
         n = [0, 1, tile - 1, tile, tile + 1, int(rng.integers(2, 300)), int(rng.integers(300, 3 * tile)),
-             int(rng.integers(tile, 6 * tile))][kind]
+             int(rng.integers(tile, 6 * tile)),
+             int(rng.integers(8 * tile, 40 * tile)) if rng.random() < 0.25 else 16 * tile - 1][kind]  # several scan groups
         w = int(rng.integers(1, tb + 1))
         v = make_values(rng, dtype, n, w)
         if dtype.kind == "i" and rng.random() < 0.3 and n:   # a negative frame of reference
