@@ -558,6 +558,7 @@ void ColumnSegment::Compact() {
 void ColumnSegment::CompactMany(DatabaseInstance &db, const std::vector<ColumnSegment *> &segments) {
 	// Batched ColumnSegment::Compact (column_segment.cpp:273-322): per (type, rule) group one upload, one
 	// adac_analyze, the width decision on the host from the downloaded min/max, one adac_pack.
+	std::lock_guard<std::mutex> flips(db.flip_lock);
 	std::map<std::pair<uint8_t, int>, std::vector<ColumnSegment *>> groups;
 	for (auto *s : segments) {
 		if (!s->NeedsCompaction()) continue;
@@ -739,6 +740,7 @@ void ColumnSegment::FinishCompaction(bool packed, uint8_t width, uint64_t mn, ui
 
 void ColumnSegment::Uncompact() {
 	// column_segment.cpp:324-346 + UncompressSuccinct :458-506
+	std::lock_guard<std::mutex> flips(db.flip_lock);
 	if (!compacted || !function || function->type != CompressionType::COMPRESSION_SUCCINCT) return;
 	std::lock_guard<std::mutex> g(bit_compression_lock);
 	const idx_t compressed_size = adac_size_in_bytes(vec_slots, vec_width);

@@ -237,6 +237,11 @@ public:
 	SegmentPool pool;
 	ColumnSegmentCatalog catalog;
 	std::atomic<int64_t> data_size {0}; // BufferManager::data_size accounting (buffer_manager.hpp:71-82)
+	// Serialises representation flips (Compact / CompactMany / Uncompact) of this database.  The reference has a
+	// single policy thread plus scan-triggered compaction and locks only the function-pointer swap; here a flip
+	// stages the unpacked rows outside the segment lock, so two concurrent flips of one segment (two policy
+	// threads, or two first scans) must not overlap.  Order: flip_lock -> bit_compression_lock -> pool.lock.
+	std::mutex flip_lock;
 	const CompressionFunction *GetCompressionFunction(CompressionType type, PhysicalType data_type);
 
 private:

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""One-off concurrency stress of the host mirror: N host threads scan / fetch random ranges of the same segments
+(ctypes releases the GIL, so the C++ paths really run in parallel) while the background policy thread flips
+representations every few milliseconds and one thread keeps calling Compact / Uncompact by hand.  Every returned
+row must equal the loaded value; the decoded-segment cache is on in half of the runs.
+usage: python tools/soak_threads.py [seconds] [threads]"""
+import importlib
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+adac = importlib.import_module("duckdb-adaptive-compression_amd")
+adac.build()
+host = importlib.import_module("duckdb-adaptive-compression_amd.host")
+
+seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0
+nthreads = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+errors = []
+for run, cache in enumerate((0, 16 << 20)):
+    rng = np.random.default_rng(100 + run)
+    db = host.Database(0, adaptive=True, arena_bytes=128 << 20, decoded_cache_bytes=cache)
+    cols = []
+    for i in range(24):
+        dtype = (np.uint32, np.int64, np.uint16)[i % 3]
+        n = int(rng.integers(3000, 30000))
+        v = (np.int64(i * 1000) + rng.integers(0, 1 << (5 + i % 11), size=n)).astype(dtype)
+        s = db.create_segment(dtype, start=i * 100000)
+        for off in range(0, n, 2048):
+            s.append(v, offset=off, count=min(2048, n - off))
+        cols.append((s, v))
+    stop = threading.Event()
+    counts = [0] * (nthreads + 1)
+
+    def reader(tid):
+        r = np.random.default_rng(1000 + tid)
+        try:
+            while not stop.is_set():
+                s, v = cols[int(r.integers(0, len(cols)))]
+                if r.random() < 0.2:
+                    row = int(r.integers(0, len(v)))
+                    if s.fetch_row(row) != v[row]:
+                        errors.append((run, tid, "fetch", row))
+                        return
+                else:
+                    a = int(r.integers(0, len(v)))
+                    k = int(r.integers(1, min(2048, len(v) - a) + 1))
+                    if not np.array_equal(s.scan(a, k), v[a:a + k]):
+                        errors.append((run, tid, "scan", a, k))
+                        return
+                counts[tid] += 1
+        except Exception as e:  # noqa: BLE001
+            errors.append((run, tid, repr(e)[:200]))
+
+    def flipper():
+        r = np.random.default_rng(7)
+        try:
+            while not stop.is_set():
+                s, _ = cols[int(r.integers(0, len(cols)))]
+                (s.compact if r.random() < 0.5 else s.uncompact)()
+                counts[nthreads] += 1
+        except Exception as e:  # noqa: BLE001
+            errors.append((run, "flipper", repr(e)[:200]))
+
+    db.enable_background(3)
+    threads = [threading.Thread(target=reader, args=(t,)) for t in range(nthreads)] + [threading.Thread(target=flipper)]
+    for t in threads:
+        t.start()
+    t_end = time.time() + seconds / 2
+    while time.time() < t_end and not errors:
+        time.sleep(0.5)
+        print("run", run, "ops", sum(counts), "errors", len(errors), flush=True)
+    stop.set()
+    for t in threads:
+        t.join()
+    db.disable_background()
+    for s, v in cols:  # final state must still read back
+        if not np.array_equal(np.concatenate([s.scan(a, min(2048, len(v) - a)) for a in range(0, len(v), 2048)]), v):
+            errors.append((run, "final readback"))
+    db.close()
+print("done: errors", errors[:5])
+sys.exit(1 if errors else 0)
