@@ -527,7 +527,10 @@ idx_t ColumnSegment::AppendRows(UnifiedVectorFormat &data, idx_t offset, idx_t a
 }
 
 idx_t ColumnSegment::Append(UnifiedVectorFormat &append_data, idx_t offset, idx_t append_count) {
-	// column_segment.cpp:247-271
+	// column_segment.cpp:247-271.  The whole append is one flip-free section: the background policy thread must
+	// not compact the segment between the Uncompact below and the write into the unpacked image (in the
+	// reference that window is open: its TSan suppressions cover it)
+	std::lock_guard<std::recursive_mutex> flips(db.flip_lock);
 	bool uncompacted = false;
 	if (IsBitCompressed()) {
 		Uncompact();
@@ -558,7 +561,7 @@ void ColumnSegment::Compact() {
 void ColumnSegment::CompactMany(DatabaseInstance &db, const std::vector<ColumnSegment *> &segments) {
 	// Batched ColumnSegment::Compact (column_segment.cpp:273-322): per (type, rule) group one upload, one
 	// adac_analyze, the width decision on the host from the downloaded min/max, one adac_pack.
-	std::lock_guard<std::mutex> flips(db.flip_lock);
+	std::lock_guard<std::recursive_mutex> flips(db.flip_lock);
 	std::map<std::pair<uint8_t, int>, std::vector<ColumnSegment *>> groups;
 	for (auto *s : segments) {
 		if (!s->NeedsCompaction()) continue;
@@ -740,7 +743,7 @@ void ColumnSegment::FinishCompaction(bool packed, uint8_t width, uint64_t mn, ui
 
 void ColumnSegment::Uncompact() {
 	// column_segment.cpp:324-346 + UncompressSuccinct :458-506
-	std::lock_guard<std::mutex> flips(db.flip_lock);
+	std::lock_guard<std::recursive_mutex> flips(db.flip_lock);
 	if (!compacted || !function || function->type != CompressionType::COMPRESSION_SUCCINCT) return;
 	std::lock_guard<std::mutex> g(bit_compression_lock);
 	const idx_t compressed_size = adac_size_in_bytes(vec_slots, vec_width);

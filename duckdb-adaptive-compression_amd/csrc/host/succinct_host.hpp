@@ -240,8 +240,9 @@ public:
 	// Serialises representation flips (Compact / CompactMany / Uncompact) of this database.  The reference has a
 	// single policy thread plus scan-triggered compaction and locks only the function-pointer swap; here a flip
 	// stages the unpacked rows outside the segment lock, so two concurrent flips of one segment (two policy
-	// threads, or two first scans) must not overlap.  Order: flip_lock -> bit_compression_lock -> pool.lock.
-	std::mutex flip_lock;
+	// threads, or two first scans) must not overlap, and an Append must not see its segment flip between its
+	// Uncompact and its write.  Order: flip_lock -> bit_compression_lock -> pool.lock.
+	std::recursive_mutex flip_lock; // recursive: Append holds it across its own Uncompact / Compact
 	const CompressionFunction *GetCompressionFunction(CompressionType type, PhysicalType data_type);
 
 private:

@@ -40,6 +40,14 @@ for run, cache in enumerate((0, 16 << 20)):
         r = np.random.default_rng(1000 + tid)
         try:
             while not stop.is_set():
+                if r.random() < 0.15 and grow:
+                    s, full, have = grow[int(r.integers(0, len(grow)))]
+                    a = int(r.integers(0, have - 64))
+                    if not np.array_equal(s.scan(a, 64), full[a:a + 64]):
+                        errors.append((run, tid, "scan of a growing segment", a))
+                        return
+                    counts[tid] += 1
+                    continue
                 s, v = cols[int(r.integers(0, len(cols)))]
                 if r.random() < 0.2:
                     row = int(r.integers(0, len(v)))
@@ -66,8 +74,41 @@ for run, cache in enumerate((0, 16 << 20)):
         except Exception as e:  # noqa: BLE001
             errors.append((run, "flipper", repr(e)[:200]))
 
+    # one writer: appends 2048-row vectors to segments of its own (also read by the readers) while they flip
+    grow = []
+    for i in range(4):
+        dtype = (np.uint32, np.int64)[i % 2]
+        full = (np.int64(77000 + i) + rng.integers(0, 1 << 9, size=60000)).astype(dtype)
+        s = db.create_segment(dtype, start=10_000_000 + i * 100000)
+        s.append(full, offset=0, count=2048)
+        grow.append([s, full, 2048])
+
+    def writer():
+        try:
+            k = 0
+            while not stop.is_set():
+                g = grow[k % len(grow)]
+                k += 1
+                s, full, have = g
+                if have + 2048 > len(full) or have + 2048 > 262136 // full.dtype.itemsize:
+                    continue
+                a = s.append(full, offset=have, count=2048)
+                if a != 2048:
+                    errors.append((run, "writer", "short append", a))
+                    return
+                g[2] = have + 2048
+                lo = int(np.random.default_rng(k).integers(0, g[2] - 100))
+                if not np.array_equal(s.scan(lo, 100), full[lo:lo + 100]):
+                    errors.append((run, "writer", "readback", lo))
+                    return
+                counts[nthreads] += 1
+                time.sleep(0.0005)
+        except Exception as e:  # noqa: BLE001
+            errors.append((run, "writer", repr(e)[:200]))
+
     db.enable_background(3)
-    threads = [threading.Thread(target=reader, args=(t,)) for t in range(nthreads)] + [threading.Thread(target=flipper)]
+    threads = [threading.Thread(target=reader, args=(t,)) for t in range(nthreads)] + [threading.Thread(target=flipper),
+                                                                                      threading.Thread(target=writer)]
     for t in threads:
         t.start()
     t_end = time.time() + seconds / 2
@@ -78,6 +119,9 @@ for run, cache in enumerate((0, 16 << 20)):
     for t in threads:
         t.join()
     db.disable_background()
+    for s, full, have in grow:
+        if not np.array_equal(np.concatenate([s.scan(a, min(2048, have - a)) for a in range(0, have, 2048)]), full[:have]):
+            errors.append((run, "final readback of a grown segment"))
     for s, v in cols:  # final state must still read back
         if not np.array_equal(np.concatenate([s.scan(a, min(2048, len(v) - a)) for a in range(0, len(v), 2048)]), v):
             errors.append((run, "final readback"))
