@@ -142,3 +142,28 @@ def test_persistent_block_image(adac, oracle, golden):
     for bad in (good[:-1], good + b"\0", b"\0" * 8 + bytes([0]) + good[9:], good[:8] + bytes([40]) + good[9:]):
         with pytest.raises(adac.AdacError):
             adac.block_read(bad)
+
+
+def test_null_arguments_are_refused_not_dereferenced(adac):
+    """Every entry point called with NULL handles / pointers and zero sizes: status-returning ones answer
+    ADAC_ERR_INVALID_ARGUMENT (or NO_DEVICE for adac_ctx_create-like calls), getters answer 0 / NULL, destroy
+    functions accept NULL — nothing dereferences a NULL handle (errors are statuses, never crashes: the C++ adapter
+    turns them into InternalException, SURVEY.md §8b 'Errors')."""
+    import ctypes as C
+    L = adac.lib()
+    host_only = {"adac_status_string", "adac_last_error", "adac_abi_version", "adac_type_is_supported", "adac_type_size",
+                 "adac_hi", "adac_width", "adac_packed_words", "adac_size_in_bytes", "adac_arena_words",
+                 "adac_tile_values", "adac_set_tuning", "adac_block_bytes", "adac_stored_min", "adac_block_write",
+                 "adac_bp_plan_encodable"}
+    for name, (res, args) in adac.SIGNATURES.items():
+        if name in host_only:
+            continue
+        zero = [None if (a is C.c_void_p or a is C.c_char_p or (isinstance(a, type) and issubclass(a, C._Pointer))) else 0
+                for a in args]
+        r = getattr(L, name)(*zero)
+        if res is C.c_int:
+            assert r != 0, name                      # an adac_status other than ADAC_OK
+        elif res is None:
+            assert r is None
+        else:
+            assert not r or r == -1, (name, r)       # counts are 0, pointers NULL, adac_ctx_device(NULL) is -1
