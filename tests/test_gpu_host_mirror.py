@@ -375,3 +375,80 @@ def test_all_sixteen_plugin_slots_and_the_checkpoint_side_pipeline(adac, oracle,
         assert np.array_equal(got[ok], (vals.astype(np.int32) - 500_000)[row:row + s.count][ok])
         row += s.count
     db.close()
+
+
+def test_concurrent_flips_appends_and_scans(adac, host):
+    """Regression guard for two races found by tools/soak_threads.py: two representation flips of one segment
+    overlapping (background policy thread + a second flipper), and the policy thread compacting a segment between
+    an Append's Uncompact and its write.  Readers on six threads must always see the loaded rows."""
+    import threading
+    import time
+    rng = np.random.default_rng(33)
+    db = host.Database(0, adaptive=True, arena_bytes=64 << 20, decoded_cache_bytes=4 << 20)
+    errors = []
+    try:
+        cols = []
+        for i in range(10):
+            dtype = (np.uint32, np.int64)[i % 2]
+            v = (np.int64(i * 500) + rng.integers(0, 1 << (6 + i), size=12000)).astype(dtype)
+            s = db.create_segment(dtype, start=i * 50000)
+            for off in range(0, len(v), 2048):
+                s.append(v, offset=off, count=min(2048, len(v) - off))
+            cols.append((s, v))
+        full = (900_000 + rng.integers(0, 1 << 8, size=40000)).astype(np.uint32)
+        grow = db.create_segment(np.uint32, start=9_000_000)
+        grow.append(full, offset=0, count=2048)
+        have = [2048]
+        stop = threading.Event()
+
+        def reader(tid):
+            r = np.random.default_rng(tid)
+            try:
+                while not stop.is_set():
+                    if r.random() < 0.2:
+                        a = int(r.integers(0, have[0] - 32))
+                        ok = np.array_equal(grow.scan(a, 32), full[a:a + 32])
+                    else:
+                        s, v = cols[int(r.integers(0, len(cols)))]
+                        a = int(r.integers(0, len(v) - 1))
+                        k = int(r.integers(1, min(2048, len(v) - a) + 1))
+                        ok = np.array_equal(s.scan(a, k), v[a:a + k])
+                    if not ok:
+                        errors.append(("mismatch", tid))
+                        return
+            except Exception as e:  # noqa: BLE001
+                errors.append((tid, repr(e)[:200]))
+
+        def flipper():
+            r = np.random.default_rng(99)
+            try:
+                while not stop.is_set():
+                    s, _ = cols[int(r.integers(0, len(cols)))]
+                    (s.compact if r.random() < 0.5 else s.uncompact)()
+            except Exception as e:  # noqa: BLE001
+                errors.append(("flipper", repr(e)[:200]))
+
+        def writer():
+            try:
+                while not stop.is_set() and have[0] + 2048 <= len(full):
+                    assert grow.append(full, offset=have[0], count=2048) == 2048
+                    have[0] += 2048
+                    time.sleep(0.002)
+            except Exception as e:  # noqa: BLE001
+                errors.append(("writer", repr(e)[:200]))
+
+        db.enable_background(3)
+        threads = [threading.Thread(target=reader, args=(t,)) for t in range(6)]
+        threads += [threading.Thread(target=flipper), threading.Thread(target=writer)]
+        for t in threads:
+            t.start()
+        time.sleep(1.5)
+        stop.set()
+        for t in threads:
+            t.join()
+        db.disable_background()
+        assert not errors, errors[:3]
+        assert np.array_equal(np.concatenate([grow.scan(a, min(2048, have[0] - a)) for a in range(0, have[0], 2048)]),
+                              full[:have[0]])
+    finally:
+        db.close()
