@@ -239,6 +239,7 @@ def test_adaptive_policy_round(adac, oracle, host):
         db.close()
 
 
+@pytest.mark.timeout(120)
 def test_background_thread_compacts_while_scanning(adac, host):
     """The detached policy thread of the reference (column_segment_catalog.cpp:13-22), with a short period:
     scans keep returning correct rows while representations flip underneath."""
@@ -377,6 +378,7 @@ def test_all_sixteen_plugin_slots_and_the_checkpoint_side_pipeline(adac, oracle,
     db.close()
 
 
+@pytest.mark.timeout(120)
 def test_concurrent_flips_appends_and_scans(adac, host):
     """Regression guard for two races found by tools/soak_threads.py: two representation flips of one segment
     overlapping (background policy thread + a second flipper), and the policy thread compacting a segment between
