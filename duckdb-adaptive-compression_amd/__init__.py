@@ -102,6 +102,7 @@ SIGNATURES = {
     "adac_dev_memset": (_int, [_vp, _vp, _int, _sz]),
     "adac_memcpy_h2d": (_int, [_vp, _vp, _vp, _sz]),
     "adac_memcpy_d2h": (_int, [_vp, _vp, _vp, _sz]),
+    "adac_memcpy_d2h_async": (_int, [_vp, _vp, _vp, _sz]),
     "adac_host_alloc_pinned": (_int, [_vp, _sz, _P(_vp)]),
     "adac_host_free_pinned": (_int, [_vp, _vp]),
     "adac_timer_start": (_int, [_vp]),

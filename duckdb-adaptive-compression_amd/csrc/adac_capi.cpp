@@ -304,6 +304,14 @@ extern "C" adac_status adac_memcpy_d2h(adac_ctx *c, void *dst, const void *d_src
 	return ADAC_OK;
 }
 
+extern "C" adac_status adac_memcpy_d2h_async(adac_ctx *c, void *dst, const void *d_src, size_t bytes) {
+	if (!c || ((!dst || !d_src) && bytes)) return ADAC_ERR_INVALID_ARGUMENT;
+	if (bytes == 0) return ADAC_OK;
+	ADAC_HIP(hipSetDevice(c->device));
+	ADAC_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+	return ADAC_OK;
+}
+
 extern "C" adac_status adac_host_alloc_pinned(adac_ctx *c, size_t bytes, void **ptr) {
 	if (!c || !ptr) return ADAC_ERR_INVALID_ARGUMENT;
 	ADAC_HIP(hipSetDevice(c->device));

@@ -58,6 +58,7 @@ const uint8_t *SegmentPool::CacheLookup(const void *key) {
 	}
 	cache_hits++;
 	it->second.stamp = ++cache_clock;
+	CacheSettle(it->second);
 	return it->second.data;
 }
 
@@ -71,7 +72,15 @@ void SegmentPool::CacheReserve() {
 	for (size_t i = nslots; i-- > 0;) cache_free_slots.push_back((int32_t)i);
 }
 
+void SegmentPool::CacheSettle(CacheEntry &e) {
+	if (e.pending) {
+		Check(adac_ctx_sync(ctx), "adac_ctx_sync(prefetch)"); // one stream: everything queued before it is done too
+		for (auto &kv : cache) kv.second.pending = false;
+	}
+}
+
 static void CacheRelease(SegmentPool &pool, SegmentPool::CacheEntry &e) {
+	pool.CacheSettle(e); // the DMA may still be writing the block
 	if (e.slot >= 0) {
 		pool.cache_free_slots.push_back(e.slot);
 	} else {
@@ -123,6 +132,7 @@ SegmentPool::~SegmentPool() {
 	}
 	if (cache_slab) adac_host_free_pinned(ctx, cache_slab);
 	if (h_pinned) adac_host_free_pinned(ctx, h_pinned);
+	if (d_prefetch) adac_dev_free(ctx, d_prefetch);
 	if (d_staging) adac_dev_free(ctx, d_staging);
 	if (d_staging2) adac_dev_free(ctx, d_staging2);
 	if (d_arena) adac_dev_free(ctx, d_arena);
@@ -188,6 +198,9 @@ uint8_t *SegmentPool::PinnedStaging(size_t bytes) {
 
 void *SegmentPool::Staging(size_t bytes) {
 	return Grow(ctx, d_staging, staging_bytes, bytes + 64);
+}
+void *SegmentPool::PrefetchStaging(size_t bytes) {
+	return Grow(ctx, d_prefetch, prefetch_bytes, bytes + 64);
 }
 void *SegmentPool::Staging2(size_t bytes) {
 	return Grow(ctx, d_staging2, staging2_bytes, bytes + 64);
@@ -415,8 +428,23 @@ ColumnSegment::ColumnSegment(DatabaseInstance &db_p, PhysicalType type_p, idx_t 
 	db.catalog.AddColumnSegment(this);
 }
 
+void ColumnSegment::SetNext(ColumnSegment *next) {
+	std::lock_guard<std::mutex> g(db.pool.lock); // the prefetch path follows the hint under this lock
+	if (next_hint) next_hint->prev_hint = nullptr;
+	next_hint = next;
+	if (next) {
+		if (next->prev_hint) next->prev_hint->next_hint = nullptr;
+		next->prev_hint = this;
+	}
+}
+
 ColumnSegment::~ColumnSegment() {
 	db.catalog.RemoveColumnSegment(this);
+	{
+		std::lock_guard<std::mutex> g(db.pool.lock);
+		if (prev_hint) prev_hint->next_hint = nullptr;
+		if (next_hint) next_hint->prev_hint = nullptr;
+	}
 	if (packed_on_device) {
 		std::lock_guard<std::mutex> g(db.pool.lock);
 		db.pool.Free(word_off, arena_words);
@@ -470,7 +498,10 @@ void ColumnSegment::ScanRows(idx_t start_row, idx_t scan_count, data_ptr_t targe
 		std::lock_guard<std::mutex> pg(db.pool.lock);
 		if (db.pool.cache_capacity) {
 			// vector-serving cache: decode the WHOLE segment once, serve this and the following vectors by memcpy
-			const uint8_t *hit = db.pool.CacheLookup(this);
+			auto found = db.pool.cache.find(this);
+			const bool was_prefetched = found != db.pool.cache.end() && found->second.pending;
+			const uint8_t *hit = db.pool.CacheLookup(this); // waits for a prefetch in flight
+			bool fresh = was_prefetched;
 			if (!hit) {
 				uint8_t *block = db.pool.CacheInsert(this, count * type_size);
 				if (block) {
@@ -478,11 +509,16 @@ void ColumnSegment::ScanRows(idx_t start_row, idx_t scan_count, data_ptr_t targe
 					Check(adac_unpack_range(LayoutOf(device_layout), db.pool.d_arena, layout_index, 0, count, d_all, 0),
 					      "adac_unpack_range");
 					Check(adac_memcpy_d2h(db.pool.ctx, block, d_all, count * type_size), "adac_memcpy_d2h");
+					for (auto &kv : db.pool.cache) kv.second.pending = false; // synchronous copy on the one stream
 					hit = block;
+					fresh = true;
 				}
 			}
 			if (hit) {
+				// first touch of this segment's image: once the rows are out, start the next segment's decode + copy,
+				// so that it runs while the consumer reads this one (a sequential scan then waits for PCIe once)
 				std::memcpy(target, hit + start_row * type_size, scan_count * type_size);
+				if (fresh && next_hint) next_hint->PrefetchIntoCache(this);
 				return;
 			}
 		}
@@ -498,6 +534,34 @@ void ColumnSegment::ScanRows(idx_t start_row, idx_t scan_count, data_ptr_t targe
 		// unpacked slots / uncompressed block: the bytes ARE the values (no min add: SURVEY.md §8a (iii))
 		std::memcpy(target, raw.data() + start_row * type_size, scan_count * type_size);
 	}
+}
+
+void ColumnSegment::PrefetchIntoCache(const ColumnSegment *reader) {
+	// called with pool.lock held by a scan of the PREVIOUS segment (`reader`).  This segment's state is read under
+	// its own lock, taken with try_lock only: a flip in progress on it holds that lock and may be waiting for
+	// pool.lock.
+	std::unique_lock<std::mutex> g(bit_compression_lock, std::try_to_lock);
+	if (!g.owns_lock()) return;
+	if (!function || function->type != CompressionType::COMPRESSION_SUCCINCT || !packed_on_device || count == 0) return;
+	auto &pool = db.pool;
+	if (pool.cache.count(this)) return;
+	for (auto &kv : pool.cache) {
+		if (kv.second.pending) return; // one prefetch in flight at a time (one staging buffer)
+	}
+	const size_t bytes = count * type_size;
+	const bool slotted = pool.cache_slab && bytes <= SegmentPool::kCacheSlotBytes;
+	const size_t charge = slotted ? SegmentPool::kCacheSlotBytes : bytes;
+	const bool evicts = pool.cache_used + charge > pool.cache_capacity || (slotted && pool.cache_free_slots.empty());
+	// never at the reader's expense: its block was touched last, so with two or more entries the victim is another
+	if (evicts && (pool.cache.size() < 2 || !pool.cache.count(reader))) return;
+	uint8_t *block = pool.CacheInsert(this, bytes);
+	if (!block) return;
+	void *d_all = pool.PrefetchStaging(bytes);
+	Check(adac_unpack_range(LayoutOf(device_layout), pool.d_arena, layout_index, 0, count, d_all, 0), "adac_unpack_range");
+	Check(adac_memcpy_d2h_async(pool.ctx, block, d_all, bytes), "adac_memcpy_d2h_async");
+	pool.cache[this].pending = true;
+	pool.cache_misses++; // a device decode of this segment, as a miss would have been; the look-up will be a hit
+	pool.cache_prefetches++;
 }
 
 idx_t ColumnSegment::AppendRows(UnifiedVectorFormat &data, idx_t offset, idx_t append_count) {
@@ -1076,6 +1140,10 @@ extern "C" int adach_function_slots(adach_db *h, int compression_type, int physi
 		                         (const void *)fn->finalize_append, (const void *)fn->revert_append};
 		for (int i = 0; i < 16; i++) present[i] = slots[i] != nullptr;
 	});
+}
+
+extern "C" int adach_segment_set_next(adach_segment *s, adach_segment *next) {
+	return Guard([&]() { s->seg->SetNext(next ? next->seg.get() : nullptr); });
 }
 
 extern "C" void adach_segment_destroy(adach_segment *s) {

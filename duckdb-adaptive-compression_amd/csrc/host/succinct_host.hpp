@@ -169,6 +169,7 @@ public:
 		size_t bytes = 0;
 		uint64_t stamp = 0;
 		int32_t slot = -1; // >= 0: a slot of the slab; -1: its own page-locked allocation (oversized segment)
+		bool pending = false; // a prefetch (decode + async copy on the pool's stream) is still in flight
 	};
 	uint64_t cache_capacity = 0, cache_used = 0, cache_clock = 0, cache_hits = 0, cache_misses = 0;
 	std::unordered_map<const void *, CacheEntry> cache;
@@ -178,6 +179,9 @@ public:
 	uint8_t *cache_slab = nullptr;
 	std::vector<int32_t> cache_free_slots;
 	void CacheReserve(); // allocates the slab (idempotent); called when a cache capacity is configured
+	void *PrefetchStaging(size_t bytes); // device scratch of the in-flight prefetch (separate from Staging)
+	void CacheSettle(CacheEntry &e);     // waits for the entry's prefetch, if any
+	uint64_t cache_prefetches = 0;
 	const uint8_t *CacheLookup(const void *key);
 	uint8_t *CacheInsert(const void *key, size_t bytes); // evicts least-recently-used entries; nullptr if too big
 	void CacheDrop(const void *key);
@@ -185,6 +189,8 @@ public:
 private:
 	std::map<uint64_t, uint64_t> free_list; // offset -> length
 	uint64_t used_words = 0;
+	void *d_prefetch = nullptr;
+	size_t prefetch_bytes = 0;
 	void *d_staging = nullptr;
 	size_t staging_bytes = 0;
 	void *d_staging2 = nullptr;
@@ -264,6 +270,11 @@ public:
 	const CompressionFunction *function;
 	bool succinct_possible;
 	bool is_data_segment = true;
+	// SegmentBase::next (src/include/duckdb/storage/table/segment_base.hpp): the following segment of the column.
+	// Not owned; used only as a hint to start decoding it while the consumer is still reading this one.
+	ColumnSegment *next_hint = nullptr;
+	ColumnSegment *prev_hint = nullptr; // so that a destroyed segment can unlink itself
+	void SetNext(ColumnSegment *next);
 
 	void Scan(ColumnScanState &state, idx_t scan_count, Vector &result, idx_t result_offset, bool entire_vector);
 	void FetchRow(ColumnFetchState &state, row_t row_id, Vector &result, idx_t result_idx);
@@ -301,6 +312,8 @@ public:
 
 	// codec internals reached by the CompressionFunction callbacks
 	void ScanRows(idx_t start_row, idx_t scan_count, data_ptr_t target);
+	// decode + async copy of THIS segment into the pool's cache, on behalf of a scan of `reader` (pool.lock held)
+	void PrefetchIntoCache(const ColumnSegment *reader);
 	idx_t AppendRows(UnifiedVectorFormat &data, idx_t offset, idx_t count);
 
 	ColumnSegment(DatabaseInstance &db, PhysicalType type, idx_t start, idx_t segment_size, const CompressionFunction *fn,

@@ -24,6 +24,7 @@ HOST_SIGNATURES = {
                                      C.POINTER(_u64), C.POINTER(_u64)]),
     "adach_function_slots": (_int, [_vp, _int, _int, C.POINTER(_int)]),
     "adach_segment_create": (_vp, [_vp, _int, _u64, _u64]),
+    "adach_segment_set_next": (_int, [_vp, _vp]),
     "adach_segment_destroy": (None, [_vp]),
     "adach_segment_append": (_i64, [_vp, _vp, _vp, _vp, _u64, _u64]),
     "adach_segment_scan": (_int, [_vp, _u64, _u64, _vp, _u64, _int]),
@@ -100,8 +101,13 @@ class Database:
         except Exception:  # pragma: no cover
             pass
 
-    def create_segment(self, dtype, start=0, segment_size=262136):
+    def create_segment(self, dtype, start=0, segment_size=262136, chain=True):
+        """chain: make the new segment the `next` of the previously created one when it continues the same column
+        (same type, start right after it) — the hint the sequential-scan prefetch follows."""
         s = Segment(self, dtype, start, segment_size)
+        prev = self.segments[-1] if self.segments else None
+        if chain and prev is not None and prev._h and prev.dtype == s.dtype and start > prev.start:
+            _ok(hlib().adach_segment_set_next(prev._h, s._h), "SetNext")
         self.segments.append(s)
         return s
 

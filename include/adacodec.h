@@ -162,6 +162,9 @@ adac_status adac_dev_memset(adac_ctx *ctx, void *d_ptr, int byte, size_t bytes);
 adac_status adac_memcpy_h2d(adac_ctx *ctx, void *d_dst, const void *src, size_t bytes); /* blocking */
 adac_status adac_memcpy_d2h(adac_ctx *ctx, void *dst, const void *d_src, size_t bytes); /* blocking */
 
+/* Device-to-host copy enqueued on the context's stream without waiting for it (dst should be page-locked,
+ * adac_host_alloc_pinned, for the copy to overlap host work); adac_ctx_sync makes the bytes visible. */
+adac_status adac_memcpy_d2h_async(adac_ctx *ctx, void *dst, const void *d_src, size_t bytes);
 /* Page-locked host memory for staging (hipHostMalloc): D2H/H2D copies of it run at PCIe line rate. */
 adac_status adac_host_alloc_pinned(adac_ctx *ctx, size_t bytes, void **ptr);
 adac_status adac_host_free_pinned(adac_ctx *ctx, void *ptr);

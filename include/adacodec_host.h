@@ -63,6 +63,9 @@ int adach_compress_column(adach_db *db, int compression_type, int physical_type,
 int adach_function_slots(adach_db *db, int compression_type, int physical_type, int *present);
 
 adach_segment *adach_segment_create(adach_db *db, int physical_type, uint64_t start, uint64_t segment_size);
+/* SegmentBase::next as a hint: with the decoded-segment cache on, the first scan of `seg` also starts decoding and
+ * copying `next` on the pool's stream, so a sequential scan overlaps PCIe with the consumer.  NULL unlinks. */
+int adach_segment_set_next(adach_segment *seg, adach_segment *next);
 void adach_segment_destroy(adach_segment *seg);
 /* returns rows consumed (the caller opens a new segment for the rest), -1 on error */
 int64_t adach_segment_append(adach_segment *seg, const void *vals, const uint64_t *validity, const uint32_t *sel,
