@@ -31,6 +31,12 @@ _TYPE2NP = {v: k for k, v in _NP2TYPE.items()}
 
 STATUS_NAMES = {0: "OK", 1: "INVALID_ARGUMENT", 2: "UNSUPPORTED_TYPE", 3: "DEVICE", 4: "OUT_OF_MEMORY", 5: "NO_DEVICE"}
 
+UNPACK_JOB_DTYPE = np.dtype([
+    ("word_off", np.uint64), ("min", np.uint64), ("out_off", np.uint64), ("start", np.uint32), ("count", np.uint32),
+    ("width", np.uint8), ("flags", np.uint8), ("reserved", np.uint16), ("reserved2", np.uint32),
+])
+assert UNPACK_JOB_DTYPE.itemsize == 40
+
 SEGMENT_DESC_DTYPE = np.dtype([
     ("word_off", np.uint64), ("val_off", np.uint64), ("min", np.uint64), ("count", np.uint32),
     ("width", np.uint8), ("flags", np.uint8), ("reserved", np.uint16),
@@ -90,6 +96,10 @@ SIGNATURES = {
     "adac_block_bytes": (_u64, [_u64, _u8]),
     "adac_block_write": (_u64, [_vp, _int, _vp, _vp, _u64]),
     "adac_block_read": (_int, [_vp, _u64, _vp, _P(_int), _vp, _u64]),
+    "adac_block_peek": (_int, [_vp, _u64, _vp, _P(_int)]),
+    "adac_block_stride": (_u64, [_u64, _u8]),
+    "adac_blocks_write": (_int, [_vp, _int, _vp, _vp, _u64, _vp, _vp]),
+    "adac_blocks_read": (_int, [_vp, _int, _vp, _vp, _u64, _vp, _vp]),
     "adac_tile_values": (_u32, [_int]),
     "adac_set_tuning": (_int, [C.c_char_p, _int]),
     "adac_ctx_create": (_int, [_int, _vp, _P(_vp)]),
@@ -129,6 +139,11 @@ SIGNATURES = {
     "adac_unpack": (_int, [_vp, _vp, _vp]),
     "adac_unpack_range": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _u64]),
     "adac_fetch_rows": (_int, [_vp, _vp, _vp, _vp, _u64, _vp]),
+    "adac_unpack_jobs": (_int, [_vp, _int, _vp, _u64, _vp, _vp]),
+    "adac_event_record": (_int, [_vp, _P(_vp)]),
+    "adac_event_wait": (_int, [_vp]),
+    "adac_event_done": (_int, [_vp]),
+    "adac_event_destroy": (None, [_vp]),
     "adac_capture_begin": (_int, [_vp]),
     "adac_capture_end": (_int, [_vp, C.POINTER(_vp)]),
     "adac_graph_launch": (_int, [_vp]),
@@ -239,6 +254,35 @@ def block_read(block):
     return d[0], numpy_dtype(t.value), words[:nw]
 
 
+def block_peek(block):
+    """-> (desc record, numpy dtype) from the header and trailer of a block image (exact or 8-byte padded length)."""
+    buf = np.frombuffer(block, dtype=np.uint8)
+    d = np.zeros(1, dtype=SEGMENT_DESC_DTYPE)
+    t = _int()
+    _check(lib().adac_block_peek(buf.ctypes.data, len(buf), d.ctypes.data, C.byref(t)), "adac_block_peek")
+    return d[0], numpy_dtype(t.value)
+
+
+def block_stride(count, w):
+    return lib().adac_block_stride(count, w)
+
+
+def blocks_write(ctx, dtype, descs, block_offs, d_words, d_blocks):
+    """Block images of many segments built in HBM (adac_blocks_write); synchronous."""
+    descs = np.ascontiguousarray(descs, dtype=SEGMENT_DESC_DTYPE)
+    offs = np.ascontiguousarray(block_offs, dtype=np.uint64)
+    _check(lib().adac_blocks_write(ctx._h, physical_type(dtype), descs.ctypes.data, offs.ctypes.data, len(descs),
+                                   _dptr(d_words), _dptr(d_blocks)), "adac_blocks_write")
+
+
+def blocks_read(ctx, dtype, descs, block_offs, d_blocks, d_words):
+    """Packed words of many block images moved into the arena at descs[i].word_off (adac_blocks_read); synchronous."""
+    descs = np.ascontiguousarray(descs, dtype=SEGMENT_DESC_DTYPE)
+    offs = np.ascontiguousarray(block_offs, dtype=np.uint64)
+    _check(lib().adac_blocks_read(ctx._h, physical_type(dtype), descs.ctypes.data, offs.ctypes.data, len(descs),
+                                  _dptr(d_blocks), _dptr(d_words)), "adac_blocks_read")
+
+
 def set_tuning(name, value):
     if lib().adac_set_tuning(name.encode(), int(value)) != 0:
         raise ValueError("unknown tuning knob %r" % name)
@@ -343,6 +387,47 @@ class Context:
         ms = C.c_float()
         _check(lib().adac_timer_stop(self._h, C.byref(ms)), "adac_timer_stop")
         return ms.value
+
+
+def unpack_jobs(ctx, dtype, jobs, d_words, d_out):
+    """Layout-free decode of a list of (segment, row range) jobs (UNPACK_JOB_DTYPE records) in one launch per 48."""
+    jobs = np.ascontiguousarray(jobs, dtype=UNPACK_JOB_DTYPE)
+    _check(lib().adac_unpack_jobs(ctx._h, physical_type(dtype), jobs.ctypes.data, len(jobs), _dptr(d_words),
+                                  _dptr(d_out)), "adac_unpack_jobs")
+
+
+def jobs_from_descs(descs, ranges, out_offs):
+    """descs: SEGMENT_DESC_DTYPE records; ranges: (start, count) per job; out_offs: element offsets."""
+    jobs = np.zeros(len(descs), dtype=UNPACK_JOB_DTYPE)
+    for i, (d, (st, c), o) in enumerate(zip(descs, ranges, out_offs)):
+        jobs[i] = (d["word_off"], d["min"], o, st, c, d["width"], d["flags"], 0, 0)
+    return jobs
+
+
+class Event:
+    """A marker in the context's stream (adac_event): wait() blocks until everything enqueued before it is done."""
+
+    def __init__(self, ctx):
+        h = _vp()
+        _check(lib().adac_event_record(ctx._h, C.byref(h)), "adac_event_record")
+        self._h = h.value
+
+    def wait(self):
+        _check(lib().adac_event_wait(self._h), "adac_event_wait")
+
+    def done(self):
+        return bool(lib().adac_event_done(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().adac_event_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pragma: no cover
+            pass
 
 
 class Graph:

@@ -58,6 +58,7 @@ struct adac_layout {
 	bool is_signed = false;
 	uint64_t null_bits = 0; // NullValue<T>() as the bit pattern of T, zero-extended (null_value.hpp:26-28)
 	uint64_t nseg = 0, ntiles = 0, total_values = 0, value_span = 0, max_arena_words = 0;
+	bool dense_values = true; // segments back to back from element 0: no element index between them is unowned
 	std::vector<uint32_t> counts;
 	std::vector<uint64_t> val_offs;
 	adac_segment_desc *d_descs = nullptr;
@@ -77,6 +78,7 @@ struct adac_layout {
 };
 
 static adac_status descs_changed(adac_layout *l);
+static adac_status ensure_scan_groups(adac_layout *l);
 
 // ------------------------------------------------------------------------------------------------
 // host-only helpers
@@ -197,6 +199,111 @@ extern "C" adac_status adac_block_read(const void *block, uint64_t len, adac_seg
 	return ADAC_OK;
 }
 
+extern "C" uint64_t adac_block_stride(uint64_t count, uint8_t width) {
+	return 8 * (adac_packed_words(count, width) + 4); // the image zero-padded to whole 8-byte units
+}
+
+extern "C" adac_status adac_block_peek(const void *block, uint64_t len, adac_segment_desc *d, int *physical_type) {
+	// header + trailer only: what a loader needs to size the arena before the words move (adac_blocks_read)
+	if (!block || !d || len < 9 + ADAC_BLOCK_TRAILER_BYTES) return ADAC_ERR_INVALID_ARGUMENT;
+	const uint8_t *p = static_cast<const uint8_t *>(block);
+	uint64_t bit_size;
+	std::memcpy(&bit_size, p, 8);
+	const uint8_t width = p[8];
+	if (width == 0 || width > 64 || bit_size % width != 0) return ADAC_ERR_INVALID_ARGUMENT;
+	const uint64_t count = bit_size / width;
+	if (count > 0xffffffffull) return ADAC_ERR_INVALID_ARGUMENT;
+	const uint64_t nwords = (bit_size + 63) >> 6;
+	// len may be the exact image or the image padded to 8 bytes (adac_block_stride)
+	if (len != 9 + nwords * 8 + ADAC_BLOCK_TRAILER_BYTES && len != 8 * (nwords + 4)) return ADAC_ERR_INVALID_ARGUMENT;
+	const uint8_t *t = p + 9 + nwords * 8;
+	const int type = t[9];
+	if (!adac_type_is_supported(type)) return ADAC_ERR_UNSUPPORTED_TYPE;
+	const uint32_t full_w = 8 * adac_type_size(type);
+	const uint8_t flags = t[8];
+	if (width > full_w || (!(flags & ADAC_SEG_PACKED) && width != full_w)) return ADAC_ERR_INVALID_ARGUMENT;
+	std::memset(d, 0, sizeof(*d));
+	std::memcpy(&d->min, t, 8);
+	d->count = (uint32_t)count;
+	d->width = width;
+	d->flags = flags;
+	if (physical_type) *physical_type = type;
+	return ADAC_OK;
+}
+
+static adac_status blocks_jobs(int physical_type, const adac_segment_desc *descs, const uint64_t *block_offs,
+                               uint64_t nseg, std::vector<adac::BlockJob> &jobs, uint32_t &max_units) {
+	if (!adac_type_is_supported(physical_type)) return ADAC_ERR_UNSUPPORTED_TYPE;
+	if (nseg && (!descs || !block_offs)) return ADAC_ERR_INVALID_ARGUMENT;
+	const uint32_t full_w = 8 * adac_type_size(physical_type);
+	jobs.resize(nseg);
+	max_units = 0;
+	for (uint64_t i = 0; i < nseg; i++) {
+		const adac_segment_desc &d = descs[i];
+		if (d.width == 0 || d.width > full_w || (d.word_off & 15) || (block_offs[i] & 7)) return ADAC_ERR_INVALID_ARGUMENT;
+		if (!(d.flags & ADAC_SEG_PACKED) && d.width != full_w) return ADAC_ERR_INVALID_ARGUMENT;
+		adac::BlockJob &j = jobs[i];
+		std::memset(&j, 0, sizeof j);
+		j.word_off = d.word_off;
+		j.block_off = block_offs[i];
+		j.min = d.min;
+		j.bit_size = (uint64_t)d.count * d.width;
+		j.nwords = (uint32_t)adac_packed_words(d.count, d.width);
+		j.arena_words = (uint32_t)adac_arena_words(d.count, d.width);
+		j.width = d.width;
+		j.flags = d.flags;
+		j.type = (uint8_t)physical_type;
+		const uint32_t units = j.arena_words > j.nwords + 4 ? j.arena_words : j.nwords + 4;
+		if (units > max_units) max_units = units;
+	}
+	return ADAC_OK;
+}
+
+extern "C" adac_status adac_blocks_write(adac_ctx *ctx, int physical_type, const adac_segment_desc *descs,
+                                         const uint64_t *block_offs, uint64_t nseg, const uint64_t *d_words,
+                                         void *d_blocks) {
+	if (!ctx || (nseg && (!d_words || !d_blocks)) || ((uintptr_t)d_blocks & 7)) return ADAC_ERR_INVALID_ARGUMENT;
+	std::vector<adac::BlockJob> jobs;
+	uint32_t max_units = 0;
+	adac_status st = blocks_jobs(physical_type, descs, block_offs, nseg, jobs, max_units);
+	if (st != ADAC_OK || nseg == 0) return st;
+	ADAC_HIP(hipSetDevice(ctx->device));
+	adac::BlockJob *d_jobs = nullptr;
+	ADAC_HIP(hipMalloc((void **)&d_jobs, nseg * sizeof(adac::BlockJob)));
+	hipError_t e = hipMemcpyAsync(d_jobs, jobs.data(), nseg * sizeof(adac::BlockJob), hipMemcpyHostToDevice, ctx->stream);
+	if (e == hipSuccess) e = adac::launch_blocks_write(ctx->stream, d_jobs, nseg, max_units, d_words, d_blocks);
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream); // the job table is a local: done before it goes
+	(void)hipFree(d_jobs);
+	ADAC_HIP(e);
+	return ADAC_OK;
+}
+
+extern "C" adac_status adac_blocks_read(adac_ctx *ctx, int physical_type, const adac_segment_desc *descs,
+                                        const uint64_t *block_offs, uint64_t nseg, const void *d_blocks,
+                                        uint64_t *d_words) {
+	if (!ctx || (nseg && (!d_words || !d_blocks)) || ((uintptr_t)d_blocks & 7) || ((uintptr_t)d_words & 15))
+		return ADAC_ERR_INVALID_ARGUMENT;
+	std::vector<adac::BlockJob> jobs;
+	uint32_t max_units = 0;
+	adac_status st = blocks_jobs(physical_type, descs, block_offs, nseg, jobs, max_units);
+	if (st != ADAC_OK || nseg == 0) return st;
+	ADAC_HIP(hipSetDevice(ctx->device));
+	void *d_scratch = nullptr;
+	const size_t jobs_bytes = nseg * sizeof(adac::BlockJob);
+	ADAC_HIP(hipMalloc(&d_scratch, jobs_bytes + 16));
+	adac::BlockJob *d_jobs = static_cast<adac::BlockJob *>(d_scratch);
+	uint32_t *d_bad = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(d_scratch) + jobs_bytes);
+	uint32_t bad = 0;
+	hipError_t e = hipMemcpyAsync(d_jobs, jobs.data(), jobs_bytes, hipMemcpyHostToDevice, ctx->stream);
+	if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, 16, ctx->stream);
+	if (e == hipSuccess) e = adac::launch_blocks_read(ctx->stream, d_jobs, nseg, max_units, d_blocks, d_words, d_bad);
+	if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, ctx->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	(void)hipFree(d_scratch);
+	ADAC_HIP(e);
+	return bad ? ADAC_ERR_INVALID_ARGUMENT : ADAC_OK; // an image whose header is not the one the descriptor was made from
+}
+
 extern "C" uint32_t adac_tile_values(int t) {
 	uint32_t ts = adac_type_size(t);
 	return ts ? adac::tile_values(ts) : 0;
@@ -207,6 +314,8 @@ extern "C" int adac_set_tuning(const char *name, int value) {
 	const std::string n(name);
 	if (n == "persistent_unpack") adac::g_tuning.persistent_unpack = value;
 	else if (n == "scan_probe") adac::g_tuning.scan_probe = value;
+	else if (n == "sel_debug") adac::g_tuning.sel_debug = value;
+	else if (n == "grouped_repack") adac::g_tuning.grouped_repack = value;
 	else if (n == "templated_scan") adac::g_tuning.templated_scan = value;
 	else if (n == "scan_tiles_per_wg" && value >= 0) adac::g_tuning.scan_tiles_per_wg = value; // 0 = by type
 	else if (n == "blocks_per_cu" && value > 0) adac::g_tuning.blocks_per_cu = value;
@@ -430,6 +539,7 @@ extern "C" adac_status adac_layout_create(adac_ctx *c, int type, const uint32_t 
 	for (uint64_t s = 0; s < nseg; s++) {
 		const uint64_t off = val_offs ? val_offs[s] : run;
 		l->val_offs[s] = off;
+		if (off != run) l->dense_values = false;
 		run = off + counts[s];
 		if (off + counts[s] > l->value_span) l->value_span = off + counts[s];
 		l->total_values += counts[s];
@@ -615,6 +725,13 @@ extern "C" adac_status adac_analyze_packed(adac_layout *src, const uint64_t *d_s
 	if ((!d_src_words && src->total_values) || !aligned16(d_src_words)) return ADAC_ERR_INVALID_ARGUMENT;
 	ADAC_HIP(hipSetDevice(src->ctx->device));
 	ADAC_HIP(adac::launch_minmax_init(src->ctx->stream, dst->d_minmax, dst->nseg));
+	if (adac::g_tuning.grouped_repack) {
+		adac_status gst = ensure_scan_groups(src);
+		if (gst != ADAC_OK) return gst;
+		ADAC_HIP(adac::launch_analyze_packed_g(src->ctx->stream, src->type_size, src->is_signed, src->null_bits, rule,
+		                                       src->d_groups, src->ngroups, d_src_words, d_validity, dst->d_minmax));
+		return ADAC_OK;
+	}
 	ADAC_HIP(adac::launch_analyze_packed(src->ctx->stream, src->type_size, src->is_signed, src->null_bits, rule,
 	                                     src->d_descs, src->d_tiles, src->ntiles, d_src_words, d_validity,
 	                                     dst->d_minmax));
@@ -628,6 +745,13 @@ extern "C" adac_status adac_repack(adac_layout *src, const uint64_t *d_src_words
 	if (!aligned16(d_src_words) || !aligned16(d_dst_words) || d_src_words == d_dst_words)
 		return ADAC_ERR_INVALID_ARGUMENT;
 	ADAC_HIP(hipSetDevice(src->ctx->device));
+	if (adac::g_tuning.grouped_repack) {
+		adac_status gst = ensure_scan_groups(src);
+		if (gst != ADAC_OK) return gst;
+		ADAC_HIP(adac::launch_repack_g(src->ctx->stream, src->type_size, src->null_bits, src->d_groups, src->ngroups,
+		                               dst->d_descs, d_src_words, d_validity, d_dst_words));
+		return ADAC_OK;
+	}
 	ADAC_HIP(adac::launch_repack(src->ctx->stream, src->type_size, src->null_bits, src->d_descs, dst->d_descs,
 	                             src->d_tiles, src->ntiles, d_src_words, d_validity, d_dst_words));
 	return ADAC_OK;
@@ -662,6 +786,90 @@ extern "C" adac_status adac_unpack_range(adac_layout *l, const uint64_t *d_words
 	return ADAC_OK;
 }
 
+extern "C" adac_status adac_unpack_jobs(adac_ctx *ctx, int physical_type, const adac_unpack_job *jobs, uint64_t njobs,
+                                        const uint64_t *d_words, void *d_out) {
+	if (!ctx) return ADAC_ERR_INVALID_ARGUMENT;
+	if (!adac_type_is_supported(physical_type)) return ADAC_ERR_UNSUPPORTED_TYPE;
+	if (njobs == 0) return ADAC_OK;
+	if (!jobs || !d_words || !d_out || !aligned16(d_words)) return ADAC_ERR_INVALID_ARGUMENT;
+	const uint32_t ts = adac_type_size(physical_type);
+	if ((uintptr_t)d_out % ts) return ADAC_ERR_INVALID_ARGUMENT;
+	const uint32_t tile = adac::tile_values(ts);
+	for (uint64_t i = 0; i < njobs; i++) {
+		const adac_unpack_job &j = jobs[i];
+		if (j.width == 0 || j.width > 8 * ts || (j.word_off & 15)) return ADAC_ERR_INVALID_ARGUMENT;
+		if ((uint64_t)j.start + j.count > 0xffffffffull) return ADAC_ERR_INVALID_ARGUMENT;
+	}
+	ADAC_HIP(hipSetDevice(ctx->device));
+	// the store path wants chunk alignment relative to a 16-byte aligned base: fold d_out's own misalignment into
+	// the element offsets
+	const uint64_t bias = ((uintptr_t)d_out & 15) / ts;
+	void *base = static_cast<uint8_t *>(d_out) - bias * ts;
+	adac::UnpackJobTable table;
+	std::memset(&table, 0, sizeof table);
+	for (uint64_t i = 0; i < njobs; i++) {
+		const adac_unpack_job &j = jobs[i];
+		if (j.count) {
+			adac::UnpackJob &u = table.jobs[table.njobs++];
+			u.word_off = j.word_off;
+			u.add = ((j.flags & ADAC_SEG_PACKED) && j.min != ADAC_NO_MIN) ? j.min : 0ull;
+			u.out_off = j.out_off + bias;
+			u.start = j.start;
+			u.count = j.count;
+			u.width = j.width;
+			u.tile0 = table.ntiles;
+			table.ntiles += (j.count + tile - 1) / tile;
+		}
+		if (table.njobs == (uint32_t)adac::kMaxUnpackJobs || (i + 1 == njobs && table.njobs)) {
+			ADAC_HIP(adac::launch_unpack_jobs(ctx->stream, ts, table, d_words, base));
+			table.njobs = table.ntiles = 0;
+		}
+	}
+	return ADAC_OK;
+}
+
+struct adac_event {
+	adac_ctx *ctx = nullptr;
+	hipEvent_t ev = nullptr;
+};
+
+extern "C" adac_status adac_event_record(adac_ctx *ctx, adac_event **out) {
+	if (!ctx || !out) return ADAC_ERR_INVALID_ARGUMENT;
+	ADAC_HIP(hipSetDevice(ctx->device));
+	hipEvent_t ev = nullptr;
+	ADAC_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+	hipError_t e = hipEventRecord(ev, ctx->stream);
+	if (e != hipSuccess) {
+		(void)hipEventDestroy(ev);
+		return fail_hip(e, "hipEventRecord");
+	}
+	adac_event *h = new (std::nothrow) adac_event();
+	if (!h) {
+		(void)hipEventDestroy(ev);
+		return ADAC_ERR_OUT_OF_MEMORY;
+	}
+	ctx_retain(ctx);
+	h->ctx = ctx;
+	h->ev = ev;
+	*out = h;
+	return ADAC_OK;
+}
+
+extern "C" adac_status adac_event_wait(adac_event *ev) {
+	if (!ev) return ADAC_ERR_INVALID_ARGUMENT;
+	ADAC_HIP(hipEventSynchronize(ev->ev));
+	return ADAC_OK;
+}
+
+extern "C" int adac_event_done(adac_event *ev) { return ev && hipEventQuery(ev->ev) == hipSuccess; }
+
+extern "C" void adac_event_destroy(adac_event *ev) {
+	if (!ev) return;
+	(void)hipEventDestroy(ev->ev);
+	ctx_release(ev->ctx);
+	delete ev;
+}
+
 extern "C" adac_status adac_fetch_rows(adac_layout *l, const uint64_t *d_words, const uint32_t *d_segs,
                                        const uint32_t *d_rows, uint64_t n, void *d_out) {
 	if (!l) return ADAC_ERR_INVALID_ARGUMENT;
@@ -684,6 +892,7 @@ static adac_status ensure_scan_groups(adac_layout *l) {
 	if (per < 1) { // by type: best of 1 .. 32 tiles in tools/ab_tuning.py (u8 and u16 want more rows per workgroup)
 		per = l->type_size == 8 ? 12 : l->type_size == 4 ? 6 : l->type_size == 2 ? 8 : 4;
 	}
+	if ((uint64_t)per * tile > 65536) per = (int)(65536 / tile); // the selection scan's LDS image holds 64 Ki rows
 	if (l->groups_tiles != per) {
 		std::vector<adac::ScanGroupRef> refs;
 		for (uint64_t s = 0; s < l->nseg; s++) {
@@ -755,17 +964,27 @@ static adac_status scan_range(adac_layout *l, const uint64_t *d_words, const uin
 	if (!aligned16(d_words)) return ADAC_ERR_INVALID_ARGUMENT;
 	ADAC_HIP(hipSetDevice(l->ctx->device));
 	if (l->nseg) ADAC_HIP(hipMemsetAsync(d_counts, 0, l->nseg * sizeof(uint64_t), l->ctx->stream));
-	if (want_bitmap && l->value_span) { // edge words are OR-ed in: the bitmap starts clear
-		ADAC_HIP(hipMemsetAsync(d_bitmap, 0, ((l->value_span + 63) / 64) * sizeof(uint64_t), l->ctx->stream));
-	}
 	// order-preserving map of T onto unsigned numbers: flip the sign bit of the signed types
 	const uint32_t bits = 8 * l->type_size;
 	const uint64_t umask = bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);
 	const uint64_t sbit = l->is_signed ? (1ull << (bits - 1)) : 0ull;
 	const uint64_t blo = (lo & umask) ^ sbit, bhi = (hi & umask) ^ sbit;
+	// The scan writes every bitmap word that lies inside a group whole (zero words included) and ORs only into the
+	// words two groups share.  With the segments back to back in the value space that covers the whole bitmap, so
+	// only those shared words are zeroed first (a tiny kernel instead of a full clearing pass: 12.5 MB at C2);
+	// value spaces with gaps between segments, and the empty range, take the full memset.
+	const bool edges_only = want_bitmap && l->dense_values && bhi >= blo && l->ntiles;
+	if (want_bitmap && l->value_span && !edges_only) {
+		ADAC_HIP(hipMemsetAsync(d_bitmap, 0, ((l->value_span + 63) / 64) * sizeof(uint64_t), l->ctx->stream));
+	}
 	if (bhi < blo) return ADAC_OK; // empty range: all counts (and bits) stay zero
 	adac_status gst = ensure_scan_groups(l);
 	if (gst != ADAC_OK) return gst;
+	if (edges_only) {
+		const uint64_t words32 = (l->value_span + 31) / 32; // the odd half of the last 64-bit word, if there is one
+		ADAC_HIP(adac::launch_sel_clear_edges(l->ctx->stream, l->d_groups, l->ngroups, d_bitmap,
+		                                      (words32 & 1) ? words32 : ~0ull));
+	}
 	ADAC_HIP(adac::launch_scan_count_range(l->ctx->stream, l->type_size, l->d_groups, l->ngroups, d_words, d_validity,
 	                                       blo, bhi - blo, sbit, d_counts, want_bitmap ? d_bitmap : nullptr));
 	return ADAC_OK;

@@ -46,10 +46,32 @@ struct RangeArgs {
 	uint64_t out_off;
 };
 
+// Layout-free range decode of several segments in ONE launch (adac_unpack_jobs): the jobs travel by value in the
+// kernel-argument segment, so a batch needs no device table, no upload and no allocation — what a host that serves an
+// engine vector by vector (or prefetches the next few segments of a scan) can afford per call.
+constexpr int kMaxUnpackJobs = 48;
+struct UnpackJob {
+	uint64_t word_off; // first word of the segment in the arena
+	uint64_t add;      // frame of reference to add back (0 if none: unpacked slots, or no min)
+	uint64_t out_off;  // element offset of the job's first decoded row in the output
+	uint32_t start;    // first row of the segment to decode
+	uint32_t count;    // rows to decode
+	uint32_t width;
+	uint32_t tile0;    // first workgroup of this job in the launch
+};
+struct UnpackJobTable {
+	uint32_t njobs, ntiles;
+	UnpackJob jobs[kMaxUnpackJobs];
+};
+hipError_t launch_unpack_jobs(hipStream_t s, uint32_t type_size, const UnpackJobTable &table, const uint64_t *d_words,
+                              void *d_out);
+
 // Launch-shape knobs (adac_set_tuning): which kernel form the scan entry points use and how many persistent
 // workgroups are launched.  Defaults are the measured-best settings on MI355X.
 struct Tuning {
 	int persistent_unpack = 0;  // measured 5-15 % slower than one tile per workgroup (profiles/r01_ab_*.json)
+	int grouped_repack = 1;     // A/B: 0 = one tile per workgroup with the 16 KiB row image (the first version)
+	int sel_debug = 0;          // diagnostic: selection scan without its flush (1) / without any bitmap emit (2)
 	int scan_probe = 0;         // diagnostic: fused-scan loop + loads only (no field walk)
 	int templated_scan = 1;     // width-templated register path of the fused scans for 4 <= w <= 32
 	int scan_tiles_per_wg = 0; // tiles per fused-scan workgroup; 0 = by type (12 tiles of u64, 6 of u32, 8 of u16, 4 of u8)
@@ -84,6 +106,12 @@ hipError_t launch_analyze_packed(hipStream_t s, uint32_t type_size, bool sign_ex
 hipError_t launch_repack(hipStream_t s, uint32_t type_size, uint64_t null_bits, const adac_segment_desc *d_src_descs,
                          const adac_segment_desc *d_dst_descs, const TileRef *d_tiles, uint64_t ntiles,
                          const uint64_t *d_src_words, const uint64_t *d_validity, uint64_t *d_dst_words);
+hipError_t launch_analyze_packed_g(hipStream_t s, uint32_t type_size, bool sign_extend, uint64_t null_bits, int rule,
+                                   const ScanGroup *d_src_groups, uint64_t ngroups, const uint64_t *d_src_words,
+                                   const uint64_t *d_validity, uint64_t *d_minmax);
+hipError_t launch_repack_g(hipStream_t s, uint32_t type_size, uint64_t null_bits, const ScanGroup *d_src_groups,
+                           uint64_t ngroups, const adac_segment_desc *d_dst_descs, const uint64_t *d_src_words,
+                           const uint64_t *d_validity, uint64_t *d_dst_words);
 hipError_t launch_expand_groups(hipStream_t s, const adac_segment_desc *d_descs, const ScanGroupRef *d_refs,
                                 uint64_t ngroups, ScanGroup *d_groups);
 hipError_t launch_gather_selected(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs,
@@ -92,9 +120,27 @@ hipError_t launch_gather_selected(hipStream_t s, uint32_t type_size, const adac_
                                   uint64_t *d_block_tot, void *d_out, uint64_t *d_out_ids, uint64_t *d_total);
 hipError_t launch_scan_sum(hipStream_t s, uint32_t type_size, const ScanGroup *d_groups, uint64_t ngroups,
                            const uint64_t *d_words, const uint64_t *d_validity, uint64_t sbit, uint64_t *d_sums);
+hipError_t launch_sel_clear_edges(hipStream_t s, const ScanGroup *d_groups, uint64_t ngroups, uint64_t *d_bitmap,
+                                  uint64_t tail_word);
 hipError_t launch_scan_count_range(hipStream_t s, uint32_t type_size, const ScanGroup *d_groups, uint64_t ngroups,
                                    const uint64_t *d_words, const uint64_t *d_validity, uint64_t blo, uint64_t bspan,
                                    uint64_t sbit, uint64_t *d_counts, uint64_t *d_bitmap);
+
+// Persistent block images (adac_block_image.inl): one segment's packed words <-> its image in a block buffer.
+struct BlockJob {
+	uint64_t word_off;   // first word of the segment in the packed arena
+	uint64_t block_off;  // byte offset of its image in the block buffer, multiple of 8
+	uint64_t min;
+	uint64_t bit_size;   // count * width: the int_vector's m_size
+	uint32_t nwords;     // ceil(bit_size / 64)
+	uint32_t arena_words; // words the segment owns in the arena (parse: the tail past nwords is zeroed)
+	uint8_t width, flags, type, pad[5];
+};
+static_assert(sizeof(BlockJob) == 48, "device record");
+hipError_t launch_blocks_write(hipStream_t s, const BlockJob *d_jobs, uint64_t njobs, uint32_t max_units,
+                               const uint64_t *d_words, void *d_blocks);
+hipError_t launch_blocks_read(hipStream_t s, const BlockJob *d_jobs, uint64_t njobs, uint32_t max_units,
+                              const void *d_blocks, uint64_t *d_words, uint32_t *d_bad);
 
 // DuckDB BITPACKING segments (adac_bitpacking.inl).  Host view of one metadata group; must match BpGroup.
 struct BpGroupHost {

@@ -271,6 +271,32 @@ __global__ __launch_bounds__(kWorkgroup) void k_unpack(const adac_segment_desc *
 	decode_tile<U>(lds32, bit0, w, add, n, align, sink);
 }
 
+// k_unpack_jobs — the same decode for a short list of (segment, row range) jobs handed over BY VALUE in the kernel
+// arguments (scan_vector / scan_partial for several segments at once, compression_function.hpp:84-88): a workgroup
+// finds its job with a scalar scan over at most kMaxUnpackJobs first-tile numbers, everything else is k_unpack's
+// range form.
+template <typename U>
+__global__ __launch_bounds__(kWorkgroup) void k_unpack_jobs(const UnpackJobTable table,
+                                                            const uint64_t *__restrict__ words, U *__restrict__ out) {
+	constexpr int TILE = kTileBytes / (int)sizeof(U);
+	constexpr uint32_t K = 16 / sizeof(U);
+	__shared__ uint4 lds[kTileBytes / 16 + 2];
+	uint32_t j = 0;
+	for (uint32_t i = 1; i < table.njobs; i++) { // uniform: scalar loads from the kernarg segment
+		if (table.jobs[i].tile0 <= blockIdx.x) j = i;
+	}
+	const UnpackJob job = table.jobs[j];
+	const uint32_t done = (blockIdx.x - job.tile0) * (uint32_t)TILE;
+	const uint32_t first = job.start + done;
+	const uint32_t left = job.count - done;
+	const uint32_t n = left < (uint32_t)TILE ? left : (uint32_t)TILE;
+	const uint64_t elem0 = job.out_off + done;
+	const uint32_t bit0 = stage_packed(words + job.word_off, first, n, job.width, lds);
+	__syncthreads();
+	StoreSink<U> sink {out + elem0, n};
+	decode_tile<U>(reinterpret_cast<const uint32_t *>(lds), bit0, job.width, job.add, n, (uint32_t)(elem0 & (K - 1)), sink);
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_scan_agg — fused scans (SUM, COUNT(range), selection bitmap), nothing materialised.
 // ---------------------------------------------------------------------------------------------
@@ -329,46 +355,47 @@ __device__ __forceinline__ uint32_t field_of(const uint32_t (&nrm)[5], int j) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Selection-bitmap output of the filter scan (OP 3).  The lanes of a wave hold selection bits for ASCENDING,
-// adjacent element ranges (a lane's rows follow the previous lane's), together [E0, E1).  Each lane ORs its bits
-// into the wave's private LDS words (ds_or_b32); the wave then writes every 32-bit bitmap word that lies wholly
-// inside [E0, E1) with a plain coalesced store — no other wave owns a bit of it — and only the two edge words
-// with a global atomicOr (the bitmap is zeroed before the launch).  One wave's DS operations execute in order,
-// so no barrier is needed; the words are left zero for the next call.
+// Selection-bitmap output of the filter scan (OP 3).  A workgroup owns the rows [first, first + n) of ONE segment
+// (its ScanGroup), i.e. one contiguous bit string of the result.  Lanes OR their hit bits into a zeroed LDS image
+// of that string (ds_or_b32; positions are p = (val_off & 31) + row, so image word i is bitmap word
+// (val_off >> 5) + (p_base >> 5) + i), and after ONE barrier at the end the workgroup writes the image out: words
+// wholly inside the group with plain coalesced stores — zero words included, so the result needs no clearing
+// pass — and the two edge words, which neighbouring groups share, with a global atomicOr (a tiny kernel zeroes just
+// those before the scan).  Nothing is stored inside the scan loop: on gfx9 stores and loads share vmcnt, and a
+// store issued between a prefetch and its use made every flush wait for the store's round trip (measured: the
+// per-block flush of the first version cost as much as the whole scan, profiles/r02_select_ablation.json).
 // ---------------------------------------------------------------------------------------------
-constexpr int kSelWordsPerWave = 4 * 64 + 4; // register path: 4 iterations x (64 lanes x <= 32 rows) + straddle
+constexpr uint32_t kSelMaxRows = 65536;                 // rows of the largest scan group (ensure_scan_groups)
+constexpr uint32_t kSelImageWords = kSelMaxRows / 32 + 4;
 struct SelOut {
-	uint32_t *wave_words; // this wave's kSelWordsPerWave LDS words, zero on entry
-	uint32_t *bitmap32;   // the output bitmap viewed as little-endian 32-bit words
+	uint32_t *img;      // the workgroup's LDS image, kSelImageWords words, zero before the first sel_or
+	uint32_t *bitmap32; // the output bitmap viewed as little-endian 32-bit words
+	uint32_t p_base;    // position of bit 0 of the image: ((val_off & 31) + first) & ~31
+	int debug;          // diagnostic (adac_set_tuning "sel_debug"): 1 = no write-out, 2 = no emit at all (results wrong)
 };
 
-__device__ __forceinline__ void wave_emit_bits(const SelOut &o, uint64_t e0, uint32_t bits, uint32_t nbits) {
-	const uint64_t exec = __builtin_amdgcn_ballot_w64(true);
-	const uint32_t nact = (uint32_t)__popcll(exec);
-	const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(exec >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)exec, 0u));
-	const int first = __ffsll((unsigned long long)exec) - 1;
-	const int last = 63 - __clzll((long long)exec);
-	const uint64_t E0 = __shfl(e0, first, 64);
-	const uint64_t E1 = __shfl(e0 + nbits, last, 64);
-	const uint64_t base = E0 & ~31ull;
-	const uint32_t rel = (uint32_t)(e0 - base), sh = rel & 31u, idx = rel >> 5;
+__device__ __forceinline__ void sel_or(const SelOut &o, uint32_t p, uint32_t bits, uint32_t nbits) {
 	if (bits) {
-		atomicOr(&o.wave_words[idx], bits << sh);
-		if (sh + nbits > 32u) atomicOr(&o.wave_words[idx + 1], bits >> (32u - sh));
+		const uint32_t rel = p - o.p_base, sh = rel & 31u, idx = rel >> 5;
+		atomicOr(&o.img[idx], bits << sh);
+		if (sh + nbits > 32u) atomicOr(&o.img[idx + 1], bits >> (32u - sh));
 	}
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-	const uint32_t nwords = ((uint32_t)(E1 - base) + 31u) >> 5;
-	for (uint32_t i = rank; i < nwords; i += nact) {
-		const uint32_t v = atomicExch(&o.wave_words[i], 0u);
-		const uint64_t wb = base + 32ull * i;
-		uint32_t *g = o.bitmap32 + (wb >> 5);
-		if (wb >= E0 && wb + 32u <= E1) {
+}
+
+// after a workgroup barrier: image -> bitmap, for the group's positions [p0, p1)
+__device__ __forceinline__ void sel_write_out(const SelOut &o, uint32_t *__restrict__ seg_words32, uint32_t p0,
+                                              uint32_t p1) {
+	const uint32_t nwords = (p1 - o.p_base + 31u) >> 5;
+	for (uint32_t i = threadIdx.x; i < nwords; i += kWorkgroup) {
+		const uint32_t v = o.img[i];
+		const uint32_t wb = o.p_base + 32u * i;
+		uint32_t *g = seg_words32 + (wb >> 5);
+		if (wb >= p0 && wb + 32u <= p1) {
 			*g = v;
 		} else if (v) {
 			atomicOr(g, v);
 		}
 	}
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // Aggregate the fields of one chunk.  Exactness contract: SUM equals the sum of the MATERIALISED values, each
@@ -469,39 +496,6 @@ __device__ __forceinline__ uint32_t validity_window(const uint64_t *__restrict__
 	return (uint32_t)wnd;
 }
 
-// Register-path form of the selection output.  Here a WAVE owns a contiguous quarter of the run's chunks, so the
-// rows of its successive iterations are adjacent: it ORs the hit bits of kSelBlock iterations into its LDS image
-// and only then writes the image out (lane i owns words i, i + 64, ...): whole words with plain coalesced
-// stores, the two edge words with atomicOr.  All positions are 32-bit offsets `p = (val_off & 31) + row` from
-// the bitmap word holding the segment's first element; [p0, p1) is what the wave covered since the last flush.
-constexpr uint32_t kSelBlock = 4;                                  // iterations per flush
-static_assert(kSelWordsPerWave >= (int)kSelBlock * 64 + 4, "LDS image of a wave");
-
-__device__ __forceinline__ void sel_or(const SelOut &o, uint32_t p_base, uint32_t p, uint32_t bits, uint32_t nbits) {
-	if (bits) {
-		const uint32_t rel = p - p_base, sh = rel & 31u, idx = rel >> 5;
-		atomicOr(&o.wave_words[idx], bits << sh);
-		if (sh + nbits > 32u) atomicOr(&o.wave_words[idx + 1], bits >> (32u - sh));
-	}
-}
-
-__device__ __forceinline__ void sel_flush(const SelOut &o, uint32_t *__restrict__ seg_words32, uint32_t p0, uint32_t p1) {
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-	const uint32_t base = p0 & ~31u;
-	const uint32_t nwords = (p1 - base + 31u) >> 5;
-	for (uint32_t i = threadIdx.x & 63u; i < nwords; i += 64u) {
-		const uint32_t v = atomicExch(&o.wave_words[i], 0u);
-		const uint32_t wb = base + 32u * i;
-		uint32_t *g = seg_words32 + (wb >> 5);
-		if (wb >= p0 && wb + 32u <= p1) {
-			*g = v;
-		} else if (v) {
-			atomicOr(g, v);
-		}
-	}
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 template <int W, typename U, int OP, bool V>
 __device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint32_t r0, uint32_t r1,
                                            const adac_segment_desc &d, const RangePred &pred, bool linear,
@@ -510,7 +504,7 @@ __device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint
 	constexpr int MAXV = (128 + W - 1) / W;
 	constexpr uint32_t mask = W >= 32 ? 0xffffffffu : ((1u << W) - 1u);
 	constexpr bool PRED = OP == 1 || OP == 3;
-	constexpr uint32_t STRIDE = OP == 3 ? 64u : (uint32_t)kWorkgroup;
+	constexpr uint32_t STRIDE = (uint32_t)kWorkgroup;
 	const uint32_t c0 = (uint32_t)(((uint64_t)r0 * W) >> 7);       // r0 is a multiple of 128 rows
 	const uint32_t c1 = (uint32_t)(((uint64_t)r1 * W + 127) >> 7);
 	const uint32_t clast = (uint32_t)(((uint64_t)d.count * W + 127) >> 7) - 1; // last chunk holding data bits
@@ -520,35 +514,19 @@ __device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint
 		fr = field_range<U>(pred, d, mask, linear);
 		if (!fr.any) return; // zonemap-style skip: no row of this segment can satisfy the predicate
 	}
-	// lane -> chunk map.  Aggregates: the workgroup strides over the run together.  Selection: the run is cut into
-	// blocks of kSelBlock x 64 chunks dealt round-robin to the four waves; a wave walks its block in kSelBlock
-	// iterations (adjacent rows, one bitmap flush per block) and whole waves stay in the loop — Lw is the wave's
-	// first chunk of the iteration, lanes past the run carry no rows
-	constexpr uint32_t kBlockChunks = kSelBlock * 64u;
-	uint32_t L, Lw;
+	// lane -> chunk map: the workgroup strides over the run together
+	uint32_t L = c0 + threadIdx.x;
 	const uint32_t lend = c1;
-	if (OP == 3) {
-		Lw = c0 + (threadIdx.x >> 6) * kBlockChunks;
-		L = Lw + (threadIdx.x & 63u);
-	} else {
-		L = Lw = c0 + threadIdx.x;
-	}
-	if (Lw >= lend) return;
-	// selection bookkeeping (wave-uniform)
-	const uint32_t sh0 = (uint32_t)(d.val_off & 31u);
-	uint32_t *seg_words32 = sel_out.bitmap32 + (d.val_off >> 5);
-	uint32_t blk_p0 = 0, blk_iter = 0;
-	bool blk_any = false;
+	if (L >= lend) return;
+	const uint32_t sh0 = (uint32_t)(d.val_off & 31u); // selection: bit position of row 0 inside its bitmap word
 	// software pipeline: the next chunk's loads are issued (unconditionally, index clamped into the segment)
 	// before the current chunk is decoded, so a wave always has a load in flight
 	const uint32_t Lc = L < clast ? L : clast;
 	uint4 q = seg16[Lc];
 	uint32_t e = reinterpret_cast<const uint32_t *>(seg16 + (Lc < clast ? Lc + 1 : clast))[0];
-	uint32_t adv = STRIDE;
+	constexpr uint32_t adv = STRIDE;
 	uint32_t wave_count = 0; // wave-uniform (scalar) COUNT accumulator; lane 0 of the wave leaves the loop last
-	for (; Lw < lend; L += adv, Lw += adv) {
-		// selection: 64 chunks on inside a block, then on to this wave's next block
-		if (OP == 3) adv = blk_iter == kSelBlock - 1u ? (uint32_t)(kWorkgroup / 64) * kBlockChunks - (kSelBlock - 1u) * 64u : 64u;
+	for (; L < lend; L += adv) {
 		const uint32_t Lp = L + adv < clast ? L + adv : clast;
 		const uint4 qn = seg16[Lp];
 		const uint32_t en = reinterpret_cast<const uint32_t *>(seg16 + (Lp < clast ? Lp + 1 : clast))[0];
@@ -599,24 +577,7 @@ __device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint
 			// NULL rows (DuckDB validity mask over the element index space) take no part
 			if (V) hits &= validity_window(validity, d.val_off + at, have);
 			acc += (uint32_t)__popc(hits);
-			if (OP == 3) {
-				if (blk_iter == 0) {
-					const uint32_t iw0 = (128u * Lw + (W - 1)) / W;
-					blk_p0 = sh0 + (iw0 < r1 ? iw0 : r1);
-				}
-				blk_any = blk_any || __builtin_amdgcn_ballot_w64(hits != 0u) != 0ull;
-				sel_or(sel_out, blk_p0 & ~31u, sh0 + at, hits, have);
-				blk_iter++;
-				const uint32_t Lw1 = Lw + 64u < lend ? Lw + 64u : lend;
-				if (blk_iter == kSelBlock || Lw1 == lend) {
-					if (blk_any) { // nothing selected since the last flush: the bitmap is already clear there
-						const uint32_t iw1 = (128u * Lw1 + (W - 1)) / W;
-						sel_flush(sel_out, seg_words32, blk_p0, sh0 + (iw1 < r1 ? iw1 : r1));
-					}
-					blk_iter = 0;
-					blk_any = false;
-				}
-			}
+			if (OP == 3 && sel_out.debug < 2) sel_or(sel_out, sh0 + at, hits, have);
 			continue;
 		}
 		ChunkSum<W> agg;
@@ -677,6 +638,19 @@ __global__ void k_expand_groups(const adac_segment_desc *__restrict__ descs, con
 	groups[g] = out;
 }
 
+// Before a selection scan over a DENSE value space (segments back to back): zero only the bitmap words two groups
+// may share — a group's first and last word when its range does not start / end on a word boundary — and the odd
+// 32-bit half of the last 64-bit word.  Everything else is written whole by the scan itself.
+__global__ void k_sel_clear_edges(const ScanGroup *__restrict__ groups, uint64_t ngroups, uint32_t *__restrict__ bitmap32,
+                                  uint64_t tail_word) {
+	const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g == 0 && tail_word != ~0ull) bitmap32[tail_word] = 0u;
+	if (g >= ngroups) return;
+	const uint64_t p0 = groups[g].d.val_off + groups[g].first, p1 = p0 + groups[g].n;
+	if (p0 & 31u) bitmap32[p0 >> 5] = 0u;
+	if (p1 & 31u) bitmap32[p1 >> 5] = 0u;
+}
+
 // OP 0: SUM, 1: COUNT(lo <= v <= hi), 2: load-only probe, 3: COUNT + selection bitmap; V: validity mask given.
 // One workgroup per ScanGroup: up to scan_tiles_per_wg consecutive tiles of ONE segment.
 template <typename U, int OP, bool V>
@@ -686,16 +660,19 @@ __global__ __launch_bounds__(kWorkgroup, 6) void k_scan_agg(const ScanGroup *__r
                                                             uint64_t *__restrict__ result, uint32_t *__restrict__ bitmap32) {
 	constexpr uint32_t TILE = kTileBytes / sizeof(U);
 	__shared__ uint4 lds[kTileBytes / 16 + 2];
-	__shared__ uint32_t sel_words[OP == 3 ? (kWorkgroup / 64) * kSelWordsPerWave : 1];
-	SelOut sel_out {sel_words, bitmap32};
-	if (OP == 3) {
-		sel_out.wave_words = sel_words + (threadIdx.x >> 6) * kSelWordsPerWave;
-		for (uint32_t i = threadIdx.x & 63u; i < (uint32_t)kSelWordsPerWave; i += 64u) sel_out.wave_words[i] = 0u;
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-	}
+	__shared__ uint32_t sel_img[OP == 3 ? kSelImageWords : 1];
 	const uint32_t *lds32 = reinterpret_cast<const uint32_t *>(lds);
 	const ScanGroup g = groups[blockIdx.x];
 	const adac_segment_desc &d = g.d;
+	SelOut sel_out {sel_img, bitmap32, 0u, templated >> 1};
+	templated &= 1;
+	const uint32_t sel_p0 = (uint32_t)(d.val_off & 31u) + g.first; // the group's positions [sel_p0, sel_p0 + n)
+	if (OP == 3) {
+		sel_out.p_base = sel_p0 & ~31u;
+		const uint32_t nwords = (sel_p0 + g.n - sel_out.p_base + 31u) >> 5;
+		for (uint32_t i = threadIdx.x; i < nwords; i += kWorkgroup) sel_img[i] = 0u;
+		__syncthreads();
+	}
 	uint64_t acc = 0;
 	const uint32_t w = d.width;
 	const SegKind kind = seg_kind<U>(d, pred.sbit);
@@ -732,7 +709,7 @@ __global__ __launch_bounds__(kWorkgroup, 6) void k_scan_agg(const ScanGroup *__r
 					const uint32_t have = full || rest >= (uint32_t)KK ? (uint32_t)KK : rest;
 					hits &= vbits & ((1u << have) - 1u);
 					acc += (uint32_t)__popc(hits);
-					wave_emit_bits(sel_out, elem0 + (uint32_t)base, hits, have);
+					if (sel_out.debug < 2) sel_or(sel_out, (uint32_t)(d.val_off & 31u) + first + (uint32_t)base, hits, have);
 					return;
 				}
 #pragma unroll
@@ -754,6 +731,10 @@ __global__ __launch_bounds__(kWorkgroup, 6) void k_scan_agg(const ScanGroup *__r
 			__syncthreads(); // the image is rewritten by the next stage
 			done += n;
 		}
+	}
+	if (OP == 3) {
+		__syncthreads(); // every wave's bits are in the image
+		if (sel_out.debug == 0) sel_write_out(sel_out, bitmap32 + (d.val_off >> 5), sel_p0, sel_p0 + g.n);
 	}
 	const uint64_t tot = wave_sum(acc);
 	if ((threadIdx.x & 63) == 0 && tot != 0) { // wrapping sums commute: one atomic per wave and group
@@ -1243,6 +1224,216 @@ __global__ __launch_bounds__(kWorkgroup) void k_repack(const adac_segment_desc *
 }
 
 // ---------------------------------------------------------------------------------------------
+// Grouped re-compaction (the default form).  One tile per workgroup moves only n (old_w + new_w) / 8 bytes — 4 KiB at
+// 8 -> 8 bits — behind a full HBM round trip and two barriers, and the 16 KiB row image allows four workgroups per
+// CU: ~8 KiB in flight per CU, i.e. ~1.2 TB/s at narrow widths whatever the inner loops do (measured, DESIGN.md
+// §2).  Here a workgroup owns a ScanGroup of the source layout (several tiles of one segment) and walks it in stages
+// of as many whole tiles as fit 16 KiB of PACKED bytes on both sides, so the bytes in flight per workgroup no longer
+// shrink with the width; and the row image is gone: a lane combines the K rows of its chunk into one bit string of
+// K * new_w <= 128 bits in registers and ORs it into a zeroed LDS image of the OUTPUT words (ds_or_b64, one to three
+// per chunk), which the workgroup then copies out with 16-byte stores.  Adjacent lanes touch adjacent words, so
+// there is no strided LDS access left to conflict.
+// ---------------------------------------------------------------------------------------------
+// K masked fields of `w` bits (w <= 8 * sizeof(U)), row order -> the K * w-bit string {lo, hi}
+template <typename U>
+__device__ __forceinline__ void concat_fields(const U *f, uint32_t w, uint64_t &lo, uint64_t &hi) {
+	uint64_t a, b;
+	uint32_t s; // bits of a and of b
+	if (sizeof(U) == 8) {
+		a = (uint64_t)f[0];
+		b = (uint64_t)f[1];
+		s = w;
+	} else {
+		uint32_t q[4];
+		uint32_t qw; // bits of each q
+		if (sizeof(U) == 4) {
+#pragma unroll
+			for (int i = 0; i < 4; i++) q[i] = (uint32_t)f[i];
+			qw = w;
+		} else if (sizeof(U) == 2) {
+#pragma unroll
+			for (int i = 0; i < 4; i++) q[i] = (uint32_t)f[2 * i] | ((uint32_t)f[2 * i + 1] << w);
+			qw = 2 * w;
+		} else {
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				const uint32_t p0 = (uint32_t)f[4 * i] | ((uint32_t)f[4 * i + 1] << w);
+				const uint32_t p1 = (uint32_t)f[4 * i + 2] | ((uint32_t)f[4 * i + 3] << w);
+				q[i] = p0 | (p1 << (2 * w));
+			}
+			qw = 4 * w;
+		}
+		a = (uint64_t)q[0] | ((uint64_t)q[1] << qw); // qw <= 32
+		b = (uint64_t)q[2] | ((uint64_t)q[3] << qw);
+		s = 2 * qw;
+	}
+	lo = s >= 64 ? a : (a | (b << s));
+	hi = s >= 64 ? b : (b >> (64 - s)); // s >= 1
+}
+
+// OR the string {lo, hi} into the zeroed 64-bit word image at bit position p (ds_or_b64; words that get no bit are
+// skipped, so narrow strings cost one atomic)
+__device__ __forceinline__ void image_or(unsigned long long *img, uint32_t p, uint64_t lo, uint64_t hi) {
+	const uint32_t idx = p >> 6, sh = p & 63u;
+	const uint64_t o0 = lo << sh;
+	const uint64_t o1 = sh ? ((lo >> (64 - sh)) | (hi << sh)) : hi;
+	const uint64_t o2 = sh ? (hi >> (64 - sh)) : 0ull;
+	if (o0) atomicOr(&img[idx], (unsigned long long)o0);
+	if (o1) atomicOr(&img[idx + 1], (unsigned long long)o1);
+	if (o2) atomicOr(&img[idx + 2], (unsigned long long)o2);
+}
+
+// whole tiles of a stage: both packed sides within 16 KiB
+template <typename U>
+__device__ __forceinline__ uint32_t stage_tiles(uint32_t w_a, uint32_t w_b) {
+	constexpr uint32_t TILE = kTileBytes / sizeof(U);
+	const uint32_t w = w_a > w_b ? w_a : w_b;
+	const uint32_t fit = (8u * kTileBytes) / (TILE * w);
+	return fit < 1u ? 1u : fit;
+}
+
+template <typename U>
+__global__ __launch_bounds__(kWorkgroup) void k_repack_g(const ScanGroup *__restrict__ src_groups,
+                                                         const adac_segment_desc *__restrict__ dst_descs,
+                                                         const uint64_t *__restrict__ src_words,
+                                                         const uint64_t *__restrict__ validity, uint64_t null_bits,
+                                                         uint64_t *__restrict__ dst_words) {
+	constexpr uint32_t TILE = kTileBytes / sizeof(U);
+	constexpr int K = 16 / (int)sizeof(U);
+	constexpr uint32_t kImgWords = kTileBytes / 8 + 4;
+	__shared__ uint4 lds[kTileBytes / 16 + 2];
+	__shared__ __attribute__((aligned(16))) unsigned long long img[kImgWords];
+	const ScanGroup g = src_groups[blockIdx.x];
+	const adac_segment_desc &sd = g.d;
+	const adac_segment_desc dd = dst_descs[g.seg];
+	const uint32_t w_old = sd.width, w = dd.width;
+	const bool packed = (dd.flags & ADAC_SEG_PACKED) != 0;
+	const U sub = (U)((packed && dd.min != ADAC_NO_MIN) ? dd.min : 0ull); // column_segment.cpp:371-373
+	const U wmask = (U)mask64(w);
+	const uint64_t add = effective_add(sd);
+	const uint32_t fit = stage_tiles<U>(w_old, w);
+	for (uint32_t i = threadIdx.x; i < kImgWords; i += kWorkgroup) img[i] = 0ull;
+	const uint32_t *lds32 = reinterpret_cast<const uint32_t *>(lds);
+	for (uint32_t done = 0; done < g.n;) {
+		const uint32_t first = g.first + done; // a multiple of TILE: both bit streams start on a 256-byte boundary
+		const uint32_t left = g.n - done;
+		const uint32_t n = left < fit * TILE ? left : fit * TILE;
+		const uint32_t bit0 = stage_packed(src_words + sd.word_off, first, n, w_old, lds);
+		__syncthreads(); // the staged bits are visible; the image is zero (start, or the previous copy-out)
+		const uint64_t elem0 = sd.val_off + first;
+		auto sink = [&](int32_t base, const U *v, bool full) { // decode_run walks with align 0: base >= 0
+			const uint32_t rest = n - (uint32_t)base;
+			const uint32_t rows_here = full || rest >= (uint32_t)K ? (uint32_t)K : rest;
+			const uint32_t vbits = validity ? validity_window(validity, elem0 + (uint32_t)base, rows_here) : 0xffffffffu;
+			U f[K];
+#pragma unroll
+			for (int j = 0; j < K; j++) {
+				const U x = ((vbits >> j) & 1u) ? v[j] : (U)null_bits;
+				f[j] = (uint32_t)j < rows_here ? (U)((U)(x - sub) & wmask) : (U)0; // rows past the run leave no bit
+			}
+			uint64_t lo, hi;
+			concat_fields<U>(f, w, lo, hi);
+			image_or(img, (uint32_t)base * w, lo, hi);
+		};
+		if (sizeof(U) == 8 && w_old > 32) {
+			decode_run<U, true>(lds32, bit0, w_old, add, n, sink);
+		} else {
+			decode_run<U, false>(lds32, bit0, w_old, add, n, sink);
+		}
+		__syncthreads(); // every lane's bits are in the image; the staged input may be overwritten
+		const uint32_t nwords = (n * w + 63u) >> 6;
+		unsigned long long *__restrict__ dst =
+		    reinterpret_cast<unsigned long long *>(dst_words) + dd.word_off + (((uint64_t)first * w) >> 6);
+		for (uint32_t q = 2u * threadIdx.x; q < nwords; q += 2u * kWorkgroup) {
+			const unsigned long long v0 = img[q], v1 = img[q + 1];
+			img[q] = 0ull;
+			img[q + 1] = 0ull;
+			if (q + 1 < nwords) {
+				uint4 o;
+				o.x = (uint32_t)v0;
+				o.y = (uint32_t)(v0 >> 32);
+				o.z = (uint32_t)v1;
+				o.w = (uint32_t)(v1 >> 32);
+				*reinterpret_cast<uint4 *>(dst + q) = o;
+			} else {
+				dst[q] = v0;
+			}
+		}
+		done += n;
+	}
+}
+
+template <typename U>
+__global__ __launch_bounds__(kWorkgroup) void k_analyze_packed_g(const ScanGroup *__restrict__ src_groups,
+                                                                 const uint64_t *__restrict__ src_words,
+                                                                 const uint64_t *__restrict__ validity,
+                                                                 int sign_extend, uint64_t null_bits, int rule,
+                                                                 uint64_t *__restrict__ minmax) {
+	constexpr uint32_t TILE = kTileBytes / sizeof(U);
+	using S = typename std::make_signed<U>::type;
+	__shared__ uint4 lds[kTileBytes / 16 + 2];
+	__shared__ uint64_t pmin[kWorkgroup / 64], pmax[kWorkgroup / 64];
+	const ScanGroup g = src_groups[blockIdx.x];
+	const adac_segment_desc &sd = g.d;
+	const uint32_t w_old = sd.width;
+	const uint64_t add = effective_add(sd);
+	const uint32_t fit = stage_tiles<U>(w_old, w_old);
+	const uint32_t *lds32 = reinterpret_cast<const uint32_t *>(lds);
+	uint64_t mn = ~0ull, mx = 0;
+	for (uint32_t done = 0; done < g.n;) {
+		const uint32_t first = g.first + done;
+		const uint32_t left = g.n - done;
+		const uint32_t n = left < fit * TILE ? left : fit * TILE;
+		const uint32_t bit0 = stage_packed(src_words + sd.word_off, first, n, w_old, lds);
+		__syncthreads();
+		const uint64_t elem0 = sd.val_off + first;
+		auto sink = [&](int32_t base, const U *v, bool full) {
+			constexpr int K = 16 / (int)sizeof(U);
+			const uint32_t rest = n - (uint32_t)base;
+			const uint32_t rows_here = full || rest >= (uint32_t)K ? (uint32_t)K : rest;
+			const uint32_t vbits = validity ? validity_window(validity, elem0 + (uint32_t)base, rows_here) : 0xffffffffu;
+#pragma unroll
+			for (int j = 0; j < K; j++) {
+				if ((uint32_t)j >= rows_here) continue;
+				const bool valid = (vbits >> j) & 1u;
+				uint64_t x;
+				if (rule == ADAC_RULE_APPEND) { // succinct.cpp:286-287: NULL rows do not take part
+					if (!valid) continue;
+					x = sign_extend ? (uint64_t)(int64_t)(S)v[j] : (uint64_t)v[j];
+				} else { // column_segment.cpp:392-399: every slot, zero-extended; NULL slots hold NullValue<T>
+					x = valid ? (uint64_t)v[j] : null_bits;
+				}
+				mn = x < mn ? x : mn;
+				mx = x > mx ? x : mx;
+			}
+		};
+		if (sizeof(U) == 8 && w_old > 32) {
+			decode_run<U, true>(lds32, bit0, w_old, add, n, sink);
+		} else {
+			decode_run<U, false>(lds32, bit0, w_old, add, n, sink);
+		}
+		__syncthreads(); // the staged input is rewritten by the next stage
+		done += n;
+	}
+	mn = wave_min(mn);
+	mx = wave_max(mx);
+	if ((threadIdx.x & 63) == 0) {
+		pmin[threadIdx.x >> 6] = mn;
+		pmax[threadIdx.x >> 6] = mx;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+#pragma unroll
+		for (int i = 1; i < kWorkgroup / 64; i++) {
+			mn = pmin[i] < mn ? pmin[i] : mn;
+			mx = pmax[i] > mx ? pmax[i] : mx;
+		}
+		atomicMin(reinterpret_cast<unsigned long long *>(minmax + 2 * (uint64_t)g.seg), (unsigned long long)mn);
+		atomicMax(reinterpret_cast<unsigned long long *>(minmax + 2 * (uint64_t)g.seg + 1), (unsigned long long)mx);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_fetch — point look-ups straight from HBM (two 8-byte loads per row).
 // ---------------------------------------------------------------------------------------------
 template <typename U>
@@ -1277,6 +1468,7 @@ hipError_t dispatch_size(uint32_t type_size, F &&f) {
 
 #include "adac_bitpacking.inl"
 #include "adac_select_gather.inl"
+#include "adac_block_image.inl"
 
 unsigned persistent_grid(uint64_t ntiles) {
 	const uint64_t cap = (uint64_t)g_tuning.num_cus * (uint64_t)g_tuning.blocks_per_cu;
@@ -1349,6 +1541,30 @@ hipError_t launch_repack(hipStream_t s, uint32_t type_size, uint64_t null_bits, 
 	});
 }
 
+hipError_t launch_analyze_packed_g(hipStream_t s, uint32_t type_size, bool sign_extend, uint64_t null_bits, int rule,
+                                   const ScanGroup *d_src_groups, uint64_t ngroups, const uint64_t *d_src_words,
+                                   const uint64_t *d_validity, uint64_t *d_minmax) {
+	if (ngroups == 0) return hipSuccess;
+	return dispatch_size(type_size, [&](auto tag) {
+		using U = decltype(tag);
+		hipLaunchKernelGGL(k_analyze_packed_g<U>, dim3((unsigned)ngroups), dim3(kWorkgroup), 0, s, d_src_groups,
+		                   d_src_words, d_validity, sign_extend ? 1 : 0, null_bits, rule, d_minmax);
+		return hipGetLastError();
+	});
+}
+
+hipError_t launch_repack_g(hipStream_t s, uint32_t type_size, uint64_t null_bits, const ScanGroup *d_src_groups,
+                           uint64_t ngroups, const adac_segment_desc *d_dst_descs, const uint64_t *d_src_words,
+                           const uint64_t *d_validity, uint64_t *d_dst_words) {
+	if (ngroups == 0) return hipSuccess;
+	return dispatch_size(type_size, [&](auto tag) {
+		using U = decltype(tag);
+		hipLaunchKernelGGL(k_repack_g<U>, dim3((unsigned)ngroups), dim3(kWorkgroup), 0, s, d_src_groups, d_dst_descs,
+		                   d_src_words, d_validity, null_bits, d_dst_words);
+		return hipGetLastError();
+	});
+}
+
 hipError_t launch_unpack(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs, const TileRef *d_tiles,
                          uint64_t ntiles, const uint64_t *d_words, void *d_out) {
 	if (ntiles == 0) return hipSuccess;
@@ -1375,6 +1591,17 @@ hipError_t launch_unpack_range(hipStream_t s, uint32_t type_size, const adac_seg
 		const uint32_t nt = (range.count + tile - 1) / tile;
 		hipLaunchKernelGGL((k_unpack<U, true>), dim3(nt), dim3(kWorkgroup), 0, s, d_descs,
 		                   static_cast<const TileRef *>(nullptr), range, d_words, static_cast<U *>(d_out));
+		return hipGetLastError();
+	});
+}
+
+hipError_t launch_unpack_jobs(hipStream_t s, uint32_t type_size, const UnpackJobTable &table, const uint64_t *d_words,
+                              void *d_out) {
+	if (table.njobs == 0 || table.ntiles == 0) return hipSuccess;
+	return dispatch_size(type_size, [&](auto tag) {
+		using U = decltype(tag);
+		hipLaunchKernelGGL(k_unpack_jobs<U>, dim3(table.ntiles), dim3(kWorkgroup), 0, s, table, d_words,
+		                   static_cast<U *>(d_out));
 		return hipGetLastError();
 	});
 }
@@ -1421,6 +1648,13 @@ hipError_t launch_scan_sum(hipStream_t s, uint32_t type_size, const ScanGroup *d
 	});
 }
 
+hipError_t launch_sel_clear_edges(hipStream_t s, const ScanGroup *d_groups, uint64_t ngroups, uint64_t *d_bitmap,
+                                  uint64_t tail_word) {
+	hipLaunchKernelGGL(k_sel_clear_edges, dim3((unsigned)((ngroups + 255) / 256 + (ngroups == 0))), dim3(256), 0, s,
+	                   d_groups, ngroups, reinterpret_cast<uint32_t *>(d_bitmap), tail_word);
+	return hipGetLastError();
+}
+
 hipError_t launch_scan_count_range(hipStream_t s, uint32_t type_size, const ScanGroup *d_groups, uint64_t ngroups,
                                    const uint64_t *d_words, const uint64_t *d_validity, uint64_t blo, uint64_t bspan,
                                    uint64_t sbit, uint64_t *d_counts, uint64_t *d_bitmap) {
@@ -1430,7 +1664,7 @@ hipError_t launch_scan_count_range(hipStream_t s, uint32_t type_size, const Scan
 		const dim3 grid((unsigned)ngroups);
 		const RangePred pred {blo, bspan, sbit};
 		uint32_t *bm = reinterpret_cast<uint32_t *>(d_bitmap);
-		const int tpl = g_tuning.templated_scan;
+		const int tpl = g_tuning.templated_scan | (g_tuning.sel_debug << 1);
 #define ADAC_SCAN(OPN, VAL)                                                                                            \
 	hipLaunchKernelGGL((k_scan_agg<U, OPN, VAL>), grid, dim3(kWorkgroup), 0, s, d_groups, tpl, d_words, pred,         \
 	                   d_validity, d_counts, bm)
@@ -1442,6 +1676,24 @@ hipError_t launch_scan_count_range(hipStream_t s, uint32_t type_size, const Scan
 #undef ADAC_SCAN
 		return hipGetLastError();
 	});
+}
+
+hipError_t launch_blocks_write(hipStream_t s, const BlockJob *d_jobs, uint64_t njobs, uint32_t max_units,
+                               const uint64_t *d_words, void *d_blocks) {
+	if (njobs == 0) return hipSuccess;
+	const uint32_t chunks = (max_units + kImageChunk - 1) / kImageChunk;
+	hipLaunchKernelGGL(k_blocks_write, dim3((unsigned)(njobs * chunks)), dim3(kWorkgroup), 0, s, d_jobs, chunks, d_words,
+	                   static_cast<uint64_t *>(d_blocks));
+	return hipGetLastError();
+}
+
+hipError_t launch_blocks_read(hipStream_t s, const BlockJob *d_jobs, uint64_t njobs, uint32_t max_units,
+                              const void *d_blocks, uint64_t *d_words, uint32_t *d_bad) {
+	if (njobs == 0) return hipSuccess;
+	const uint32_t chunks = (max_units + kImageChunk - 1) / kImageChunk;
+	hipLaunchKernelGGL(k_blocks_read, dim3((unsigned)(njobs * chunks)), dim3(kWorkgroup), 0, s, d_jobs, chunks,
+	                   static_cast<const uint64_t *>(d_blocks), d_words, d_bad);
+	return hipGetLastError();
 }
 
 hipError_t launch_bp_prepare(hipStream_t s, uint32_t type_size, void *d_groups, uint64_t ngroups, const void *d_blocks) {

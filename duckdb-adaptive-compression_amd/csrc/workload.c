@@ -166,6 +166,59 @@ WL_API int adacw_zipf_fill(void *out, uint64_t n, unsigned elem_size, double dom
 	return 0;
 }
 
+/* Rows [row_lo, row_hi) of the GLOBAL column adacw_zipf_fill(seed) defines, written to out[0 ...): a shard's
+ * slice of one column (block b of 2^20 rows is its own mt19937 stream seeded seed + b; a slice that starts inside
+ * a block replays that block's draws up to its first row, so the values equal the global column's). */
+typedef struct {
+	void *out;
+	uint64_t row_lo, row_hi;
+	unsigned elem_size;
+	double domain, q;
+	uint32_t seed;
+	uint64_t base;
+	int tid, nthreads;
+} range_job;
+
+static void *range_worker(void *arg) {
+	range_job *j = (range_job *)arg;
+	zipf_t z;
+	zipf_init(&z, j->domain, j->q);
+	uint64_t b0 = j->row_lo / WL_BLOCK, b1 = (j->row_hi + WL_BLOCK - 1) / WL_BLOCK;
+	for (uint64_t b = b0 + (uint64_t)j->tid; b < b1; b += (uint64_t)j->nthreads) {
+		mt_t m;
+		mt_seed(&m, j->seed + (uint32_t)b);
+		uint64_t lo = b * WL_BLOCK, hi = lo + WL_BLOCK;
+		if (hi > j->row_hi) hi = j->row_hi;
+		for (uint64_t i = lo; i < hi; i++) {
+			uint64_t v = j->base + zipf_draw(&z, &m);
+			if (i >= j->row_lo) store_val(j->out, i - j->row_lo, j->elem_size, v);
+		}
+	}
+	return NULL;
+}
+
+WL_API int adacw_zipf_fill_range(void *out, uint64_t row_lo, uint64_t row_hi, unsigned elem_size, double domain,
+                                 double q, uint64_t base, uint32_t seed, int threads) {
+	if (!out || domain < 1.0 || q < 0.0 || row_hi < row_lo) return 1;
+	if (elem_size != 1 && elem_size != 2 && elem_size != 4 && elem_size != 8) return 1;
+	if (threads < 1) threads = 1;
+	if (threads > 256) threads = 256;
+	pthread_t tid[256];
+	range_job jobs[256];
+	for (int t = 0; t < threads; t++) {
+		jobs[t] = (range_job){out, row_lo, row_hi, elem_size, domain, q, seed, base, t, threads};
+		if (threads == 1) {
+			range_worker(&jobs[t]);
+		} else if (pthread_create(&tid[t], NULL, range_worker, &jobs[t]) != 0) {
+			return 2;
+		}
+	}
+	if (threads > 1) {
+		for (int t = 0; t < threads; t++) pthread_join(tid[t], NULL);
+	}
+	return 0;
+}
+
 /* The first `n` raw mt19937 outputs for a seed (self-test against the published reference stream). */
 WL_API void adacw_mt19937_stream(uint32_t seed, uint32_t *out, uint64_t n) {
 	mt_t m;

@@ -28,6 +28,19 @@ def owner_of(seg_id, nseg_global, world):
     return r
 
 
+def column_shard(total_rows, type_size, rank, world):
+    """The slice of ONE global column that `rank` owns: the column's Appender segment list (layout.py) is partitioned
+    by segment id into `world` contiguous ranges (segment_range); returns (seg_lo, seg_hi, row_lo, row_hi, counts)
+    where counts are the row counts of the rank's segments and [row_lo, row_hi) their rows in the global column.
+    The reference's unit of independence is the row group / segment (row_group_collection.cpp:119-155)."""
+    import numpy as np
+    from .layout import appender_segment_counts
+    counts = appender_segment_counts(total_rows, type_size)
+    lo, hi = segment_range(len(counts), rank, world)
+    starts = np.concatenate([[0], np.cumsum(counts.astype(np.uint64))])
+    return lo, hi, int(starts[lo]), int(starts[hi]), counts[lo:hi].copy()
+
+
 class Comm:
     """Rendezvous + the three scalar collectives the measurement needs."""
 
@@ -75,6 +88,14 @@ class Comm:
         t = self._tensor(int(x), torch.int64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return int(t.item())
+
+    def sum_u64(self, x):
+        """Sum mod 2^64 of one unsigned 64-bit value per rank (checksum of checksums): reduced as two 32-bit halves
+        so that no backend's integer overflow behaviour matters."""
+        x &= 0xFFFFFFFFFFFFFFFF
+        lo = self.sum(x & 0xFFFFFFFF)
+        hi = self.sum(x >> 32)
+        return (lo + (hi << 32)) & 0xFFFFFFFFFFFFFFFF
 
     def close(self):
         if self.dist is not None:

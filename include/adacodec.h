@@ -129,6 +129,13 @@ uint64_t adac_block_write(const adac_segment_desc *desc, int physical_type, cons
 adac_status adac_block_read(const void *block, uint64_t len, adac_segment_desc *desc, int *physical_type,
                             uint64_t *words_out, uint64_t cap_words);
 
+/* Header + trailer of a block image without touching its words (len: adac_block_bytes or adac_block_stride of
+ * the image): what a loader needs to size the arena before adac_blocks_read moves the words. */
+adac_status adac_block_peek(const void *block, uint64_t len, adac_segment_desc *desc, int *physical_type);
+/* Bytes an image occupies in a block buffer: adac_block_bytes rounded up to whole 8-byte units (zero padded),
+ * 8 * (packed_words + 4).  Images are placed at byte offsets that are multiples of 8. */
+uint64_t adac_block_stride(uint64_t count, uint8_t width);
+
 /* values per device tile for a type (16 KiB of decoded output) */
 uint32_t adac_tile_values(int physical_type);
 /* Launch-shape knobs for in-process A/B measurement: "persistent_unpack", "templated_scan", "scan_probe" (0/1),
@@ -168,6 +175,15 @@ adac_status adac_memcpy_d2h_async(adac_ctx *ctx, void *dst, const void *d_src, s
 /* Page-locked host memory for staging (hipHostMalloc): D2H/H2D copies of it run at PCIe line rate. */
 adac_status adac_host_alloc_pinned(adac_ctx *ctx, size_t bytes, void **ptr);
 adac_status adac_host_free_pinned(adac_ctx *ctx, void *ptr);
+
+/* A marker in a context's stream: adac_event_record enqueues it, adac_event_wait blocks the calling host thread until
+ * everything enqueued before it has finished (and only that: later work on the same stream is not waited for, which
+ * is what lets a host keep several decode + copy batches in flight on one stream).  Any thread may wait. */
+typedef struct adac_event adac_event;
+adac_status adac_event_record(adac_ctx *ctx, adac_event **out);
+adac_status adac_event_wait(adac_event *ev);
+int adac_event_done(adac_event *ev); /* 1 finished, 0 still running (or error) */
+void adac_event_destroy(adac_event *ev);
 
 /* HIP-graph capture of a sequence of enqueue calls on the context's stream (any of the hot-path calls below,
  * after one eager warm-up run so that lazily built launch tables exist; calls that return results to the host —
@@ -268,6 +284,26 @@ adac_status adac_unpack(adac_layout *l, const uint64_t *d_words, void *d_out);
 adac_status adac_unpack_range(adac_layout *l, const uint64_t *d_words, uint64_t seg, uint64_t start, uint64_t count,
                               void *d_out, uint64_t out_off);
 
+/* The same slots for SEVERAL segments in one launch and WITHOUT a layout: every job names its segment inline (where
+ * its words start in d_words, width, min, flags — the fields of adac_segment_desc) and a row range; rows
+ * [start, start + count) are decoded to d_out[out_off ...).  The jobs travel in the kernel arguments, so the call
+ * allocates nothing and uploads nothing: it is what a host mirror of ColumnData::ScanVector
+ * (src/storage/table/column_data.cpp:92-139) uses to serve one vector, and to decode the next few segments of a scan
+ * ahead of the consumer.  Any njobs (launched in groups of 48).  out_off * sizeof(T) need not be aligned. */
+typedef struct adac_unpack_job {
+	uint64_t word_off; /* first uint64 word of the segment in d_words (multiple of 16) */
+	uint64_t min;      /* the descriptor's min (ADAC_NO_MIN if none) */
+	uint64_t out_off;  /* element offset of the first decoded row in d_out */
+	uint32_t start;    /* first row */
+	uint32_t count;    /* rows to decode */
+	uint8_t width;     /* 1..8*sizeof(T) */
+	uint8_t flags;     /* ADAC_SEG_* */
+	uint16_t reserved;
+	uint32_t reserved2;
+} adac_unpack_job;
+adac_status adac_unpack_jobs(adac_ctx *ctx, int physical_type, const adac_unpack_job *jobs, uint64_t njobs,
+                             const uint64_t *d_words, void *d_out);
+
 /* Point fetch: d_out[k] = value at row d_rows[k] of segment d_segs[k] — the intended semantics of
  * SuccinctFetchRow (succinct.cpp:244-260; the reference implementation ignores row_id). */
 adac_status adac_fetch_rows(adac_layout *l, const uint64_t *d_words, const uint32_t *d_segs, const uint32_t *d_rows,
@@ -318,6 +354,23 @@ adac_status adac_scan_select_between(adac_layout *l, const uint64_t *d_words, co
  * never written. */
 adac_status adac_unpack_selected(adac_layout *l, const uint64_t *d_words, const uint64_t *d_bitmap, void *d_out,
                                  uint64_t *d_out_ids, uint64_t *total_out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Persistence in HBM: the block images of MANY packed segments built / parsed by one kernel, so
+ * that a checkpoint is one device pass + one device-to-host copy (and a load one host-to-device copy + one pass)
+ * instead of a copy per segment.  This is the ConvertToPersistent the reference leaves empty for SUCCINCT
+ * (src/storage/table/column_segment.cpp:529-533; the checkpoint-side Compress / FinalizeCompress slots,
+ * src/storage/compression/succinct.cpp:91-119, never reach a block).  descs[i]: the segment (word_off into d_words,
+ * count, width, min, flags); block_offs[i]: byte offset (multiple of 8) of its image in d_blocks, which spans
+ * adac_block_stride(count, width) bytes; the first adac_block_bytes of them are exactly what adac_block_write
+ * produces (sdsl::int_vector<0>::serialize + trailer).  Both calls synchronise the stream.
+ * adac_blocks_read also zeroes the segment's arena words past its packed words and returns
+ * ADAC_ERR_INVALID_ARGUMENT when an image's header does not match its descriptor (build descs with adac_block_peek).
+ * ------------------------------------------------------------------------------------------- */
+adac_status adac_blocks_write(adac_ctx *ctx, int physical_type, const adac_segment_desc *descs,
+                              const uint64_t *block_offs, uint64_t nseg, const uint64_t *d_words, void *d_blocks);
+adac_status adac_blocks_read(adac_ctx *ctx, int physical_type, const adac_segment_desc *descs,
+                             const uint64_t *block_offs, uint64_t nseg, const void *d_blocks, uint64_t *d_words);
 
 /* ---------------------------------------------------------------------------------------------
  * DuckDB BITPACKING segments — the persistent counterpart of the succinct codec, decode side.

@@ -37,6 +37,8 @@ def lib():
         sig = {
             "orc_hi": (u32, [u64]),
             "orc_size_in_bytes": (u64, [u64]),
+            "orc_serialize": (u64, [vp, u64, C.c_uint, vp]),
+            "orc_load": (u64, [vp, u64, C.POINTER(u64), C.POINTER(C.c_uint), vp, u64]),
             "orc_width_from_succinct": (u32, [u64, u64, i32]),
             "orc_width_from_uncompressed": (u32, [u64, u64, i32]),
             "orc_seg_create": (vp, [C.c_uint, i32, u64, i32, i32, i32]),
@@ -83,6 +85,26 @@ def hi(x):
 
 def size_in_bytes(bit_size):
     return lib().orc_size_in_bytes(bit_size)
+
+
+def serialize(words, bit_size, width):
+    """sdsl::int_vector<0>::serialize of a vector with these words / m_size / m_width -> bytes."""
+    words = np.ascontiguousarray(words, dtype=np.uint64)
+    assert len(words) >= (bit_size + 63) // 64
+    out = np.zeros(size_in_bytes(bit_size), dtype=np.uint8)
+    n = lib().orc_serialize(_ptr(words), bit_size, width, _ptr(out))
+    assert n == len(out)
+    return out.tobytes()
+
+
+def load(data):
+    """sdsl::int_vector<0>::load -> (bit_size, width, words)"""
+    buf = np.frombuffer(data, dtype=np.uint8)
+    bs, w = C.c_uint64(), C.c_uint()
+    words = np.zeros(max(1, len(buf) // 8), dtype=np.uint64)
+    n = lib().orc_load(_ptr(buf), len(buf), C.byref(bs), C.byref(w), _ptr(words), len(words))
+    assert n, "short image"
+    return bs.value, w.value, words[:(bs.value + 63) // 64]
 
 
 def width_from_succinct(mn, mx, padded=False):

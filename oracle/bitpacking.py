@@ -42,6 +42,12 @@ def lib():
     return _lib
 
 
+def ref_available():
+    """True when oracle/_ref has been built here.  Does NOT load it: the committed vectors under tests/golden/ exist so
+    that the reference-built library is never mapped into a test process that does not run the live comparison."""
+    return os.path.exists(_REF)
+
+
 def ref():
     """The reference's fastpforlib, or None when oracle/_ref has not been built (e.g. on the GPU box)."""
     global _ref

@@ -153,6 +153,32 @@ static inline void ivec_set(orc_ivec *v, uint64_t i, uint64_t x) {
  * (io.hpp:636-640, int_vector.hpp:602-609,1565-1578) */
 ORC_API uint64_t orc_size_in_bytes(uint64_t bit_size) { return 9 + (((bit_size + 63) >> 6) << 3); }
 
+/* int_vector<0>::serialize (int_vector.hpp:1565-1578): write_header = m_size as uint64 then m_width as uint8
+ * (:602-609), write_data = capacity() >> 6 words, capacity() = ((m_size + 63) >> 6) << 6 (:1546-1561).
+ * Returns the bytes written (== orc_size_in_bytes). */
+ORC_API uint64_t orc_serialize(const uint64_t *words, uint64_t bit_size, unsigned width, uint8_t *out) {
+	uint64_t nwords = (bit_size + 63) >> 6;
+	uint8_t w8 = (uint8_t)width;
+	memcpy(out, &bit_size, 8);
+	memcpy(out + 8, &w8, 1);
+	if (nwords) memcpy(out + 9, words, nwords * 8);
+	return 9 + nwords * 8;
+}
+/* int_vector<0>::load (int_vector.hpp:1581-1595): read_header (:593-599), bit_resize(size), read capacity() >> 6
+ * words.  Returns the bytes consumed, 0 when `len` is too short. */
+ORC_API uint64_t orc_load(const uint8_t *in, uint64_t len, uint64_t *bit_size, unsigned *width, uint64_t *words,
+                          uint64_t cap_words) {
+	uint8_t w8;
+	if (len < 9) return 0;
+	memcpy(bit_size, in, 8);
+	memcpy(&w8, in + 8, 1);
+	*width = w8;
+	uint64_t nwords = (*bit_size + 63) >> 6;
+	if (len < 9 + nwords * 8 || nwords > cap_words) return 0;
+	if (nwords) memcpy(words, in + 9, nwords * 8);
+	return 9 + nwords * 8;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * width rules
  * ---------------------------------------------------------------------------------------------- */

@@ -91,7 +91,11 @@ def main():
     json.dump(summary, open(os.path.join(here, "%s_pmc_summary.json" % tag), "w"), indent=1, sort_keys=True)
     if "k_unpack<u64>" in summary["kernels"]:
         k = summary["kernels"]["k_unpack<u64>"]
-        json.dump({"round": tag, "rows": int(rows), "kernel": "k_unpack<u64>",
+        import hashlib
+        h = hashlib.sha256()
+        for f in ("adac_kernels.hip", "adac_internal.h"):  # the same hash bench.py computes (kernel_source_sha256)
+            h.update(open(os.path.join(here, "..", "duckdb-adaptive-compression_amd", "csrc", f), "rb").read())
+        json.dump({"round": tag, "rows": int(rows), "kernel": "k_unpack<u64>", "kernel_source_sha256": h.hexdigest(),
                    "hbm_bytes_per_launch": k["hbm_bytes"], "hbm_read_bytes": k["hbm_read_bytes"],
                    "hbm_write_bytes": k["hbm_write_bytes"],
                    "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; KiB*1024; "

@@ -602,3 +602,47 @@ def test_all_ones_segment_survives_the_sentinel_collision(adac, oracle, gpu_ctx,
         lay.fetch_rows(d_words, gpu_ctx.upload(np.array([0, 3, 2], dtype=np.uint32)),
                        gpu_ctx.upload(np.array([4999, 69999, 0], dtype=np.uint32)), 3, d_f)
         assert d_f.download(dtype, 3).tolist() == [ones] * 3
+
+
+def test_unpack_jobs_layout_free_batches(adac, oracle, gpu_ctx):
+    """adac_unpack_jobs: many (segment, row range) jobs per launch, described inline (no layout), arbitrary output
+    offsets and an output pointer that is not 16-byte aligned; more than 48 jobs exercises the launch grouping."""
+    rng = np.random.default_rng(77)
+    for dtype in (np.uint64, np.int32, np.uint16, np.int8):
+        dtype = np.dtype(dtype)
+        tb = 8 * dtype.itemsize
+        tile = adac.tile_values(dtype)
+        counts = np.array([int(rng.integers(1, 3 * tile)) for _ in range(40)] + [1, tile, tile + 1], dtype=np.uint32)
+        seg_vals = [make_values(rng, dtype, int(c), int(rng.integers(1, tb + 1))) for c in counts]
+        lay, d_words, d_out, descs, _ = run_encode_decode(adac, oracle, gpu_ctx, dtype, counts, seg_vals)
+        ranges, segs = [], []
+        for _ in range(130):
+            s = int(rng.integers(0, len(counts)))
+            st = int(rng.integers(0, counts[s]))
+            c = int(rng.integers(0, counts[s] - st + 1))
+            segs.append(s)
+            ranges.append((st, c))
+        segs += [0, len(counts) - 1]
+        ranges += [(0, int(counts[0])), (0, int(counts[-1]))]
+        out_offs, run = [], 3
+        for _, c in ranges:
+            out_offs.append(run)
+            run += c + int(rng.integers(0, 5))   # ragged, unaligned placement
+        jobs = adac.jobs_from_descs([descs[s] for s in segs], ranges, out_offs)
+        total = run + 8
+        d_dst = gpu_ctx.alloc((total + 1) * dtype.itemsize + 64)
+        d_dst.upload(np.full((total + 1) * dtype.itemsize + 64, 0x77, dtype=np.uint8))
+        base = d_dst.ptr + dtype.itemsize            # element 1 of the buffer: misaligned for every type but u64... and u64
+        adac.unpack_jobs(gpu_ctx, dtype, jobs, d_words, base)
+        ev = adac.Event(gpu_ctx)
+        ev.wait()
+        assert ev.done()
+        got = d_dst.download(np.uint8, (total + 1) * dtype.itemsize).view(dtype)[1:]
+        expect = np.full(total, 0x77, dtype=np.uint8).repeat(dtype.itemsize).view(dtype).copy()
+        for s, (st, c), o in zip(segs, ranges, out_offs):
+            expect[o:o + c] = seg_vals[s][st:st + c]
+        assert np.array_equal(got, expect), dtype
+        with pytest.raises(adac.AdacError):   # a word offset that is not a multiple of 16
+            bad = jobs[:1].copy()
+            bad[0]["word_off"] += 1
+            adac.unpack_jobs(gpu_ctx, dtype, bad, d_words, base)
