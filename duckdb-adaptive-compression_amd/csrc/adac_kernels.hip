@@ -496,6 +496,13 @@ __device__ __forceinline__ uint32_t validity_window(const uint64_t *__restrict__
 	return (uint32_t)wnd;
 }
 
+// hits = 2 * hits + (d <= span).  The compare lands in VCC and is consumed as the carry-in of ONE add: two vector
+// instructions per field.  (Left to itself the compiler materialises every compare with v_cndmask and merges pairs
+// with v_or3 / v_lshl — three to four instructions per field plus s_nop hazard fillers, profiles/r02_select_isa.txt.)
+__device__ __forceinline__ void hit_shift_in(uint32_t &hits, uint32_t d, uint32_t span) {
+	asm volatile("v_cmp_ge_u32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(hits) : "v"(d), "s"(span) : "vcc");
+}
+
 template <int W, typename U, int OP, bool V>
 __device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint32_t r0, uint32_t r1,
                                            const adac_segment_desc &d, const RangePred &pred, bool linear,
@@ -570,7 +577,7 @@ __device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint
 			uint32_t hits = 0;
 #pragma unroll
 			for (int j = MAXV - 1; j >= 0; j--) {
-				hits = hits + hits + (((field_of<W>(nrm, j) - fr.flo) <= fr.span) ? 1u : 0u);
+				hit_shift_in(hits, field_of<W>(nrm, j) - fr.flo, fr.span);
 			}
 			hits &= have >= 32u ? 0xffffffffu : ((1u << have) - 1u);
 			const uint32_t at = i0 < r1 ? i0 : r1; // keeps a lane's element range inside this run
@@ -658,8 +665,13 @@ __global__ __launch_bounds__(kWorkgroup, 6) void k_scan_agg(const ScanGroup *__r
                                                             const uint64_t *__restrict__ words, RangePred pred,
                                                             const uint64_t *__restrict__ validity,
                                                             uint64_t *__restrict__ result, uint32_t *__restrict__ bitmap32) {
-	constexpr uint32_t TILE = kTileBytes / sizeof(U);
-	__shared__ uint4 lds[kTileBytes / 16 + 2];
+	// LDS: the packed image of one stage of the fallback path (the register path uses none) and, for the selection
+	// scan, the bitmap image of the group.  The selection scan halves the stage so that both fit 16.4 KiB: at
+	// 24.6 KiB only six workgroups fit a CU instead of eight, and these kernels are bound by the bytes a CU keeps
+	// in flight (measured: 3.4 -> 4.2 TB/s at w = 8 from the occupancy alone).
+	constexpr uint32_t kStageBytes = OP == 3 ? kTileBytes / 2 : kTileBytes;
+	constexpr uint32_t PER_ROUND = kWorkgroup * (16 / sizeof(U)); // rows one decode round of the workgroup covers
+	__shared__ uint4 lds[kStageBytes / 16 + 2];
 	__shared__ uint32_t sel_img[OP == 3 ? kSelImageWords : 1];
 	const uint32_t *lds32 = reinterpret_cast<const uint32_t *>(lds);
 	const ScanGroup g = groups[blockIdx.x];
@@ -686,12 +698,13 @@ __global__ __launch_bounds__(kWorkgroup, 6) void k_scan_agg(const ScanGroup *__r
 		scan_run_dispatch<U, OP, V>(w, seg16, g.first, g.first + g.n, d, pred, kind == SEG_LINEAR, validity, sel_out,
 		                            acc);
 	} else {
-		uint32_t fit = (8u * kTileBytes) / (TILE * w); // whole tiles of this width per LDS image
-		fit = fit < 1u ? 1u : fit;
-		for (uint32_t done = 0; done < g.n;) { // the group in stages of as many tiles as fit the image
-			const uint32_t first = g.first + done;
+		// the group in stages of as many whole decode rounds as fit the image (a round of 64-bit fields is 4 KiB)
+		uint32_t stage_rows = ((8u * kStageBytes) / w) / PER_ROUND * PER_ROUND;
+		stage_rows = stage_rows < PER_ROUND ? PER_ROUND : stage_rows;
+		for (uint32_t done = 0; done < g.n;) {
+			const uint32_t first = g.first + done; // a multiple of PER_ROUND rows: its bits start on a 16-byte boundary
 			const uint32_t left = g.n - done;
-			const uint32_t n = left < fit * TILE ? left : fit * TILE;
+			const uint32_t n = left < stage_rows ? left : stage_rows;
 			const uint32_t bit0 = stage_packed(words + d.word_off, first, n, w, lds);
 			__syncthreads();
 			const uint64_t elem0 = d.val_off + first;
