@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <tuple>
 
 #include "adacodec_host.h"
 
@@ -31,130 +32,137 @@ static uint64_t NullBits(PhysicalType t, idx_t type_size) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// DecodeBatch
+// ------------------------------------------------------------------------------------------------
+
+DecodeBatch::~DecodeBatch() {
+	if (ev) adac_event_destroy(ev);
+}
+
+void DecodeBatch::Publish(adac_event *e, bool ok) {
+	{
+		std::lock_guard<std::mutex> g(m);
+		ev = e;
+		state = ok ? 1 : -1;
+	}
+	cv.notify_all();
+}
+
+bool DecodeBatch::Wait() {
+	std::unique_lock<std::mutex> g(m);
+	cv.wait(g, [&] { return state != 0; });
+	if (state == 2) return true;
+	if (state < 0) return false;
+	adac_event *e = ev;
+	g.unlock();
+	const bool ok = adac_event_wait(e) == ADAC_OK; // any number of threads may wait on the same event
+	g.lock();
+	if (state == 1) state = ok ? 2 : -1;
+	return state == 2;
+}
+
+bool DecodeBatch::Finished() {
+	std::lock_guard<std::mutex> g(m);
+	if (state == 2 || state < 0) return true;
+	if (state == 1 && adac_event_done(ev)) {
+		state = 2;
+		return true;
+	}
+	return false;
+}
+
+// ------------------------------------------------------------------------------------------------
 // SegmentPool
 // ------------------------------------------------------------------------------------------------
 
-SegmentPool::SegmentPool(int device, size_t arena_bytes) {
+SegmentPool::SegmentPool(int index_p, int device_p, size_t arena_bytes, const DBConfig &config)
+    : index(index_p), device(device_p), prefetch_segments(std::max<uint32_t>(1, std::min<uint32_t>(config.prefetch_segments, 48))) {
 	Check(adac_ctx_create(device, nullptr, &ctx), "adac_ctx_create");
-	arena_words = ((arena_bytes / 8) + 15) & ~15ull;
-	if (arena_words < 16) arena_words = 16;
-	void *p = nullptr;
-	adac_status st = adac_dev_alloc(ctx, arena_words * 8, &p);
-	if (st != ADAC_OK) {
-		adac_ctx_destroy(ctx);
-		Check(st, "adac_dev_alloc(arena)");
-	}
-	d_arena = static_cast<uint64_t *>(p);
-	adac_dev_memset(ctx, d_arena, 0, arena_words * 8);
-	adac_ctx_sync(ctx);
-	free_list[0] = arena_words;
-}
-
-const uint8_t *SegmentPool::CacheLookup(const void *key) {
-	auto it = cache.find(key);
-	if (it == cache.end()) {
-		cache_misses++;
-		return nullptr;
-	}
-	cache_hits++;
-	it->second.stamp = ++cache_clock;
-	CacheSettle(it->second);
-	return it->second.data;
-}
-
-void SegmentPool::CacheReserve() {
-	if (cache_slab || cache_capacity < kCacheSlotBytes) return;
-	const size_t nslots = cache_capacity / kCacheSlotBytes;
-	void *p = nullptr;
-	if (adac_host_alloc_pinned(ctx, nslots * kCacheSlotBytes, &p) != ADAC_OK) return; // entries fall back to own blocks
-	cache_slab = static_cast<uint8_t *>(p);
-	cache_free_slots.reserve(nslots);
-	for (size_t i = nslots; i-- > 0;) cache_free_slots.push_back((int32_t)i);
-}
-
-void SegmentPool::CacheSettle(CacheEntry &e) {
-	if (e.pending) {
-		Check(adac_ctx_sync(ctx), "adac_ctx_sync(prefetch)"); // one stream: everything queued before it is done too
-		for (auto &kv : cache) kv.second.pending = false;
-	}
-}
-
-static void CacheRelease(SegmentPool &pool, SegmentPool::CacheEntry &e) {
-	pool.CacheSettle(e); // the DMA may still be writing the block
-	if (e.slot >= 0) {
-		pool.cache_free_slots.push_back(e.slot);
-	} else {
-		adac_host_free_pinned(pool.ctx, e.data);
-	}
-	pool.cache_used -= e.slot >= 0 ? SegmentPool::kCacheSlotBytes : e.bytes;
-}
-
-uint8_t *SegmentPool::CacheInsert(const void *key, size_t bytes) {
-	if (bytes > cache_capacity) return nullptr;
-	CacheReserve();
-	const bool slotted = cache_slab && bytes <= kCacheSlotBytes;
-	const size_t charge = slotted ? kCacheSlotBytes : bytes;
-	while ((cache_used + charge > cache_capacity || (slotted && cache_free_slots.empty())) && !cache.empty()) {
-		auto victim = cache.begin(); // least recently used
-		for (auto it = cache.begin(); it != cache.end(); ++it) {
-			if (it->second.stamp < victim->second.stamp) victim = it;
-		}
-		CacheRelease(*this, victim->second);
-		cache.erase(victim);
-	}
-	CacheEntry e;
-	e.bytes = bytes;
-	e.stamp = ++cache_clock;
-	if (slotted && !cache_free_slots.empty()) {
-		e.slot = cache_free_slots.back();
-		cache_free_slots.pop_back();
-		e.data = cache_slab + (size_t)e.slot * kCacheSlotBytes;
-	} else {
+	try {
+		arena_words = ((arena_bytes / 8) + 15) & ~15ull;
+		if (arena_words < 16) arena_words = 16;
 		void *p = nullptr;
-		if (adac_host_alloc_pinned(ctx, bytes, &p) != ADAC_OK) return nullptr;
-		e.data = static_cast<uint8_t *>(p);
+		Check(adac_dev_alloc(ctx, arena_words * 8, &p), "adac_dev_alloc(arena)");
+		d_arena = static_cast<uint64_t *>(p);
+		Check(adac_dev_memset(ctx, d_arena, 0, arena_words * 8), "adac_dev_memset(arena)");
+		Check(adac_ctx_sync(ctx), "adac_ctx_sync");
+		free_list[0] = arena_words;
+		cache_capacity = config.decoded_cache_bytes;
+		if (cache_capacity >= kCacheSlotBytes) {
+			// the cache's page-locked memory is ONE slab cut into block-sized slots: page-locking costs ~50 us per
+			// 256 KiB block, which made every cold segment pay more for its buffer than for its decode and copy
+			const size_t nslots = cache_capacity / kCacheSlotBytes;
+			void *slab = nullptr;
+			Check(adac_host_alloc_pinned(ctx, nslots * kCacheSlotBytes, &slab), "adac_host_alloc_pinned(cache)");
+			cache_slab = static_cast<uint8_t *>(slab);
+			for (size_t i = 0; i < nslots; i++) free_slots.insert((int32_t)i);
+			const uint32_t nlanes = std::max<uint32_t>(1, std::min<uint32_t>(config.scan_lanes, 16));
+			for (uint32_t i = 0; i < nlanes; i++) {
+				std::unique_ptr<ScanLane> lane(new ScanLane());
+				Check(adac_ctx_create(device, nullptr, &lane->ctx), "adac_ctx_create(lane)");
+				lanes.push_back(std::move(lane)); // owned from here on: the destructor releases what exists
+				Check(adac_dev_alloc(lanes.back()->ctx, (size_t)prefetch_segments * kCacheSlotBytes + 256, &lanes.back()->d_stage),
+				      "adac_dev_alloc(lane staging)");
+			}
+		} else {
+			cache_capacity = 0;
+		}
+	} catch (...) {
+		Release();
+		throw;
 	}
-	cache[key] = e;
-	cache_used += e.slot >= 0 ? kCacheSlotBytes : bytes;
-	return e.data;
-}
-
-void SegmentPool::CacheDrop(const void *key) {
-	auto it = cache.find(key);
-	if (it == cache.end()) return;
-	CacheRelease(*this, it->second);
-	cache.erase(it);
 }
 
 SegmentPool::~SegmentPool() {
-	for (auto &e : cache) {
-		if (e.second.slot < 0) adac_host_free_pinned(ctx, e.second.data);
+	Release();
+}
+
+void SegmentPool::Release() {
+	for (auto &lane : lanes) {
+		if (!lane || !lane->ctx) continue;
+		adac_ctx_sync(lane->ctx); // no copy may still be writing the slab
+		if (lane->d_stage) adac_dev_free(lane->ctx, lane->d_stage);
+		adac_ctx_destroy(lane->ctx);
+		lane->ctx = nullptr;
 	}
+	lanes.clear();
+	for (auto &kv : cache) delete kv.second;
+	cache.clear();
+	for (auto *z : zombies) delete z;
+	zombies.clear();
+	if (!ctx) return;
 	if (cache_slab) adac_host_free_pinned(ctx, cache_slab);
 	if (h_pinned) adac_host_free_pinned(ctx, h_pinned);
-	if (d_prefetch) adac_dev_free(ctx, d_prefetch);
 	if (d_staging) adac_dev_free(ctx, d_staging);
 	if (d_staging2) adac_dev_free(ctx, d_staging2);
 	if (d_arena) adac_dev_free(ctx, d_arena);
 	adac_ctx_destroy(ctx);
+	ctx = nullptr;
+	cache_slab = nullptr;
+	h_pinned = nullptr;
+	d_staging = d_staging2 = nullptr;
+	d_arena = nullptr;
 }
 
-uint64_t SegmentPool::Allocate(uint64_t words) {
+bool SegmentPool::TryAllocate(uint64_t words, uint64_t &word_off) {
 	words = (words + 15) & ~15ull;
+	std::lock_guard<std::mutex> g(arena_lock);
 	for (auto it = free_list.begin(); it != free_list.end(); ++it) {
 		if (it->second >= words) {
 			uint64_t off = it->first, len = it->second;
 			free_list.erase(it);
 			if (len > words) free_list[off + words] = len - words;
 			used_words += words;
-			return off;
+			word_off = off;
+			return true;
 		}
 	}
-	throw InternalException("adacodec: segment pool arena exhausted");
+	return false;
 }
 
 void SegmentPool::Free(uint64_t off, uint64_t words) {
 	words = (words + 15) & ~15ull;
+	std::lock_guard<std::mutex> g(arena_lock);
 	used_words -= words;
 	auto next = free_list.lower_bound(off);
 	if (next != free_list.begin()) {
@@ -172,12 +180,18 @@ void SegmentPool::Free(uint64_t off, uint64_t words) {
 	free_list[off] = words;
 }
 
+uint64_t SegmentPool::UsedWords() {
+	std::lock_guard<std::mutex> g(arena_lock);
+	return used_words;
+}
+
 static void *Grow(adac_ctx *ctx, void *&buf, size_t &have, size_t want) {
 	if (want > have) {
-		if (buf) adac_dev_free(ctx, buf);
-		buf = nullptr;
 		size_t n = std::max(want, have * 2);
 		n = (n + 255) & ~size_t(255);
+		if (buf) adac_dev_free(ctx, buf);
+		buf = nullptr;
+		have = 0;
 		Check(adac_dev_alloc(ctx, n, &buf), "adac_dev_alloc(staging)");
 		have = n;
 	}
@@ -189,6 +203,7 @@ uint8_t *SegmentPool::PinnedStaging(size_t bytes) {
 		if (h_pinned) adac_host_free_pinned(ctx, h_pinned);
 		h_pinned = nullptr;
 		size_t n = std::max(bytes, pinned_bytes * 2);
+		pinned_bytes = 0;
 		n = (n + 4095) & ~size_t(4095);
 		Check(adac_host_alloc_pinned(ctx, n, &h_pinned), "adac_host_alloc_pinned(staging)");
 		pinned_bytes = n;
@@ -199,11 +214,94 @@ uint8_t *SegmentPool::PinnedStaging(size_t bytes) {
 void *SegmentPool::Staging(size_t bytes) {
 	return Grow(ctx, d_staging, staging_bytes, bytes + 64);
 }
-void *SegmentPool::PrefetchStaging(size_t bytes) {
-	return Grow(ctx, d_prefetch, prefetch_bytes, bytes + 64);
-}
 void *SegmentPool::Staging2(size_t bytes) {
 	return Grow(ctx, d_staging2, staging2_bytes, bytes + 64);
+}
+
+ScanLane &SegmentPool::AcquireLane(std::unique_lock<std::mutex> &held) {
+	// a lane nobody is enqueueing on, starting from a rotating position; otherwise wait for that one
+	const uint32_t n = (uint32_t)lanes.size();
+	const uint32_t first = next_lane.fetch_add(1) % n;
+	for (uint32_t k = 0; k < n; k++) {
+		ScanLane &lane = *lanes[(first + k) % n];
+		held = std::unique_lock<std::mutex>(lane.lock, std::try_to_lock);
+		if (held.owns_lock()) return lane;
+	}
+	held = std::unique_lock<std::mutex>(lanes[first]->lock);
+	return *lanes[first];
+}
+
+uint64_t SegmentPool::CacheUsedBytes() {
+	std::lock_guard<std::mutex> g(cache_lock);
+	return (uint64_t)(cache.size() + zombies.size()) * kCacheSlotBytes;
+}
+
+void SegmentPool::CacheReclaimLocked() {
+	size_t k = 0;
+	for (size_t i = 0; i < zombies.size(); i++) {
+		CacheEntry *z = zombies[i];
+		if (z->pins == 0 && z->batch->Finished()) {
+			free_slots.insert(z->slot);
+			delete z;
+		} else {
+			zombies[k++] = z;
+		}
+	}
+	zombies.resize(k);
+}
+
+void SegmentPool::CacheDropLocked(uint64_t key) {
+	auto it = cache.find(key);
+	if (it == cache.end()) return;
+	CacheEntry *e = it->second;
+	cache.erase(it);
+	lru.erase(e->lru);
+	e->dropped = true;
+	if (e->pins == 0 && e->batch->Finished()) {
+		free_slots.insert(e->slot);
+		delete e;
+	} else {
+		zombies.push_back(e); // a reader still holds the block, or its copy is still in flight
+	}
+}
+
+void SegmentPool::CacheDrop(uint64_t key) {
+	if (!cache_capacity) return;
+	std::lock_guard<std::mutex> g(cache_lock);
+	CacheDropLocked(key);
+}
+
+void SegmentPool::CacheUnpin(CacheEntry *e) {
+	std::lock_guard<std::mutex> g(cache_lock);
+	e->pins--;
+	if (e->dropped && e->pins == 0) CacheReclaimLocked();
+}
+
+CacheEntry *SegmentPool::CacheInsertLocked(uint64_t key, uint64_t version, size_t bytes) {
+	if (!cache_slab || bytes > kCacheSlotBytes) return nullptr;
+	if (free_slots.empty() && !zombies.empty()) CacheReclaimLocked();
+	if (free_slots.empty()) {
+		// least recently used entry nobody reads and no transfer writes
+		for (auto it = lru.rbegin(); it != lru.rend(); ++it) {
+			CacheEntry *v = *it;
+			if (v->pins == 0 && v->batch->Finished()) {
+				CacheDropLocked(v->key);
+				break;
+			}
+		}
+	}
+	if (free_slots.empty()) return nullptr;
+	CacheEntry *e = new CacheEntry();
+	e->key = key;
+	e->version = version;
+	e->bytes = bytes;
+	e->slot = *free_slots.begin();
+	free_slots.erase(free_slots.begin());
+	e->data = cache_slab + (size_t)e->slot * kCacheSlotBytes;
+	lru.push_front(e);
+	e->lru = lru.begin();
+	cache[key] = e;
+	return e;
 }
 
 // ADACH_TRACE=1: wall time of the phases of a batched compaction on stderr (diagnostic only).
@@ -226,35 +324,47 @@ struct PhaseTrace {
 	}
 };
 
-// A batch layout shared by the segments compacted together (one adac_layout, many segments).
-struct LayoutHandle {
+// A transient adac_layout (analyze / pack of one batch); destroyed with the scope.
+struct LayoutGuard {
 	adac_layout *layout = nullptr;
-	~LayoutHandle() {
+	~LayoutGuard() {
 		if (layout) adac_layout_destroy(layout);
 	}
 };
 
-static adac_layout *LayoutOf(const std::shared_ptr<void> &handle) {
-	return static_cast<LayoutHandle *>(handle.get())->layout;
-}
-
 // ------------------------------------------------------------------------------------------------
 // CompressionFunction tables
 // ------------------------------------------------------------------------------------------------
+
+// What init_scan hands to the engine for a segment of this codec: the pin on the segment's decoded image in the
+// pool's page-locked cache (the analogue of the buffer handle FixedSizeInitScan pins,
+// fixed_size_uncompressed.cpp:125-130).  Taken lazily by the first scan_vector call.
+struct SuccinctScanState : public SegmentScanState {
+	SegmentPool *pool = nullptr;
+	CacheEntry *pin = nullptr;
+	uint64_t segment_id = 0, version = 0;
+	void Release() {
+		if (pin) pool->CacheUnpin(pin);
+		pin = nullptr;
+	}
+	~SuccinctScanState() override {
+		Release();
+	}
+};
 
 static void CodecScanPartial(ColumnSegment &segment, ColumnScanState &state, idx_t scan_count, Vector &result,
                              idx_t result_offset) {
 	// succinct.cpp:123-144 / fixed_size_uncompressed.cpp FixedSizeScanPartial
 	auto start = segment.GetRelativeIndex(state.row_index);
 	result.flat = true; // SetVectorType(FLAT_VECTOR)
-	segment.ScanRows(start, scan_count, result.data + result_offset * segment.type_size);
+	segment.ScanRows(&state, start, scan_count, result.data + result_offset * segment.type_size);
 }
 static void CodecScan(ColumnSegment &segment, ColumnScanState &state, idx_t scan_count, Vector &result) {
 	CodecScanPartial(segment, state, scan_count, result, 0); // succinct.cpp:232-240
 }
 static void CodecFetchRow(ColumnSegment &segment, ColumnFetchState &, row_t row_id, Vector &result, idx_t result_idx) {
 	// intended semantics of SuccinctFetchRow (succinct.cpp:244-260): one value at row_id
-	segment.ScanRows((idx_t)row_id, 1, result.data + result_idx * segment.type_size);
+	segment.ScanRows(nullptr, (idx_t)row_id, 1, result.data + result_idx * segment.type_size);
 }
 static void EmptySkip(ColumnSegment &, ColumnScanState &, idx_t) {
 }
@@ -299,19 +409,31 @@ struct SuccinctCompressState : public CompressionState {
 		current_segment = ColumnSegment::CreateTransientSegment(checkpointer.db, checkpointer.type, row_start);
 	}
 	void FlushSegment(idx_t segment_size) {
+		// ColumnCheckpointState::FlushSegment: the engine takes the segment here and calls ConvertToPersistent on it;
+		// the images of all flushed segments are produced together in Finalize (one device pass per pool)
+		if (!checkpointer.flushed_segments.empty()) checkpointer.flushed_segments.back()->SetNext(current_segment.get());
 		checkpointer.flushed_sizes.push_back(segment_size);
 		checkpointer.flushed_segments.push_back(std::move(current_segment));
 	}
 	void Finalize(idx_t segment_size) {
 		FlushSegment(segment_size);
 		current_segment.reset();
+		if (succinct) {
+			std::vector<ColumnSegment *> segs;
+			for (auto &s : checkpointer.flushed_segments) segs.push_back(s.get());
+			ColumnSegment::ConvertManyToPersistent(checkpointer.db, segs, checkpointer.flushed_blocks);
+		}
 	}
 	ColumnDataCheckpointer &checkpointer;
 	std::unique_ptr<ColumnSegment> current_segment;
+	bool succinct = true;
 };
+template <bool SUCCINCT>
 static std::unique_ptr<CompressionState> InitCompression(ColumnDataCheckpointer &checkpointer,
                                                          std::unique_ptr<AnalyzeState>) {
-	return std::unique_ptr<CompressionState>(new SuccinctCompressState(checkpointer));
+	auto state = std::unique_ptr<SuccinctCompressState>(new SuccinctCompressState(checkpointer));
+	state->succinct = SUCCINCT;
+	return std::move(state);
 }
 static void Compress(CompressionState &state_p, Vector &data, idx_t count) {
 	auto &state = static_cast<SuccinctCompressState &>(state_p);
@@ -335,9 +457,9 @@ static void FinalizeCompress(CompressionState &state_p) {
 }
 
 // FixedSizeInitScan / SuccinctInitAppend pin the segment's block (fixed_size_uncompressed.cpp:125-130,
-// succinct.cpp:264-269); here the bits are owned by the segment / the pool arena, so the states carry nothing.
+// succinct.cpp:264-269); here the scan state pins the decoded image (lazily), the append state carries nothing.
 static std::unique_ptr<SegmentScanState> CodecInitScan(ColumnSegment &) {
-	return std::unique_ptr<SegmentScanState>(new SegmentScanState());
+	return std::unique_ptr<SegmentScanState>(new SuccinctScanState());
 }
 static std::unique_ptr<CompressionAppendState> CodecInitAppend(ColumnSegment &) {
 	return std::unique_ptr<CompressionAppendState>(new CompressionAppendState());
@@ -348,8 +470,10 @@ bool SuccinctFun::TypeIsSupported(PhysicalType type) {
 }
 
 static CompressionFunction MakeFunction(CompressionType type, PhysicalType data_type) {
+	const bool succinct = type == CompressionType::COMPRESSION_SUCCINCT;
 	return CompressionFunction {type,           data_type,        FixedSizeInitAnalyze, FixedSizeAnalyze,
-	                            FixedSizeFinalAnalyze, InitCompression, Compress,        FinalizeCompress,
+	                            FixedSizeFinalAnalyze, succinct ? InitCompression<true> : InitCompression<false>,
+	                            Compress,        FinalizeCompress,
 	                            CodecInitScan,  CodecScan,        CodecScanPartial,     CodecFetchRow,
 	                            EmptySkip,      nullptr,          CodecInitAppend,      CodecAppend,
 	                            CodecFinalizeAppend, nullptr};
@@ -369,10 +493,16 @@ CompressionFunction UncompressedFun::GetFunction(PhysicalType data_type) {
 // DatabaseInstance
 // ------------------------------------------------------------------------------------------------
 
-DatabaseInstance::DatabaseInstance(int device, const DBConfig &config_p, size_t arena_bytes)
-    : config(config_p), pool(device, arena_bytes), catalog(*this) {
-	pool.cache_capacity = config.decoded_cache_bytes;
-	pool.CacheReserve();
+DatabaseInstance::DatabaseInstance(const std::vector<int> &devices, const DBConfig &config_p, size_t arena_bytes)
+    : config(config_p), catalog(*this) {
+	if (devices.empty()) throw InternalException("adacodec: a database needs at least one segment pool");
+	for (size_t i = 0; i < devices.size(); i++) {
+		pools.push_back(std::unique_ptr<SegmentPool>(new SegmentPool((int)i, devices[i], arena_bytes, config)));
+	}
+}
+
+DatabaseInstance::~DatabaseInstance() {
+	catalog.DisableBackgroundThreadCompaction(); // the policy thread uses the pools
 }
 
 const CompressionFunction *DatabaseInstance::GetCompressionFunction(CompressionType type, PhysicalType data_type) {
@@ -411,8 +541,9 @@ std::unique_ptr<ColumnSegment> ColumnSegment::CreateTransientSegment(DatabaseIns
 
 ColumnSegment::ColumnSegment(DatabaseInstance &db_p, PhysicalType type_p, idx_t start_p, idx_t segment_size_p,
                              const CompressionFunction *fn, bool succinct_possible_p, bool background_p)
-    : db(db_p), type(type_p), type_size(adac_type_size((int)type_p)), start(start_p), function(fn),
-      succinct_possible(succinct_possible_p), segment_size(segment_size_p), background_compaction_enabled(background_p) {
+    : db(db_p), segment_id(db_p.next_segment_id.fetch_add(1)), pool(db_p.PoolFor(segment_id)), type(type_p),
+      type_size(adac_type_size((int)type_p)), start(start_p), function(fn), succinct_possible(succinct_possible_p),
+      segment_size(segment_size_p), background_compaction_enabled(background_p) {
 	raw.assign(segment_size, 0);
 	if (function->type == CompressionType::COMPRESSION_SUCCINCT) {
 		// column_segment.cpp:101-105: succinct_vec.width(8*type_size); resize(segment_size / type_size)
@@ -429,7 +560,7 @@ ColumnSegment::ColumnSegment(DatabaseInstance &db_p, PhysicalType type_p, idx_t 
 }
 
 void ColumnSegment::SetNext(ColumnSegment *next) {
-	std::lock_guard<std::mutex> g(db.pool.lock); // the prefetch path follows the hint under this lock
+	std::lock_guard<std::mutex> g(db.chain_lock);
 	if (next_hint) next_hint->prev_hint = nullptr;
 	next_hint = next;
 	if (next) {
@@ -438,21 +569,23 @@ void ColumnSegment::SetNext(ColumnSegment *next) {
 	}
 }
 
+ColumnSegment *ColumnSegment::Next() {
+	std::lock_guard<std::mutex> g(db.chain_lock);
+	return next_hint;
+}
+
 ColumnSegment::~ColumnSegment() {
+	// a policy round works on this pool's segments under the pool's flip_lock and re-checks the catalog under it:
+	// once the segment is out of the catalog here, no round touches it any more
+	std::lock_guard<std::recursive_mutex> flips(pool.flip_lock);
 	db.catalog.RemoveColumnSegment(this);
 	{
-		std::lock_guard<std::mutex> g(db.pool.lock);
+		std::lock_guard<std::mutex> g(db.chain_lock);
 		if (prev_hint) prev_hint->next_hint = nullptr;
 		if (next_hint) next_hint->prev_hint = nullptr;
 	}
-	if (packed_on_device) {
-		std::lock_guard<std::mutex> g(db.pool.lock);
-		db.pool.Free(word_off, arena_words);
-	}
-	if (db.pool.cache_capacity) {
-		std::lock_guard<std::mutex> g(db.pool.lock);
-		db.pool.CacheDrop(this);
-	}
+	pool.CacheDrop(segment_id);
+	if (packed_on_device) pool.Free(word_off, arena_words);
 }
 
 idx_t ColumnSegment::GetDataSize() const {
@@ -466,15 +599,17 @@ idx_t ColumnSegment::SuccinctSize() const {
 	return function->type == CompressionType::COMPRESSION_SUCCINCT ? adac_size_in_bytes(vec_slots, vec_width) : 0;
 }
 
+void ColumnSegment::InitializeScan(ColumnScanState &state) {
+	state.scan_state = function->init_scan(*this); // column_segment.cpp:133-135
+}
+
 void ColumnSegment::Scan(ColumnScanState &state, idx_t scan_count, Vector &result, idx_t result_offset,
                          bool entire_vector) {
 	// column_segment.cpp:137-188
 	db.catalog.AddReadAccess(this);
 	if (!compacted && !background_compaction_enabled) Compact();
-	{
-		std::lock_guard<std::mutex> g(bit_compression_lock);
-		force_reinitializing_scan_state = false; // scan states carry nothing in this codec
-	}
+	// the reference re-runs init_scan under bit_compression_lock when force_reinitializing_scan_state is set; here
+	// the scan state carries the representation version it pinned, and ScanRows re-pins on a mismatch
 	if (entire_vector) {
 		function->scan_vector(*this, state, scan_count, result);
 	} else {
@@ -490,78 +625,197 @@ void ColumnSegment::FetchRow(ColumnFetchState &state, row_t row_id, Vector &resu
 	function->fetch_row(*this, state, row_id - (row_t)start, result, result_idx); // column_segment.cpp:193-195
 }
 
-void ColumnSegment::ScanRows(idx_t start_row, idx_t scan_count, data_ptr_t target) {
+adac_segment_desc ColumnSegment::DeviceDesc() const {
+	adac_segment_desc d;
+	d.word_off = word_off;
+	d.val_off = 0;
+	d.min = device_min;
+	d.count = (uint32_t)count;
+	d.width = vec_width;
+	d.flags = ADAC_SEG_PACKED;
+	d.reserved = 0;
+	return d;
+}
+
+// One row range of this (packed) segment as a layout-free decode job.
+static adac_unpack_job MakeJob(const adac_segment_desc &d, idx_t start_row, idx_t rows, uint64_t out_off) {
+	adac_unpack_job j;
+	std::memset(&j, 0, sizeof j);
+	j.word_off = d.word_off;
+	j.min = d.min;
+	j.out_off = out_off;
+	j.start = (uint32_t)start_row;
+	j.count = (uint32_t)rows;
+	j.width = d.width;
+	j.flags = d.flags;
+	return j;
+}
+
+void ColumnSegment::DecodeRowsDirect(idx_t start_row, idx_t scan_count, data_ptr_t target) {
+	// uncached read (bit_compression_lock held): one decode launch on the pool's main stream + a copy down into the
+	// page-locked bounce block (a direct DMA), then the few KiB move into the engine's pageable vector
+	std::lock_guard<std::mutex> pg(pool.lock);
+	void *d_out = pool.Staging(scan_count * type_size);
+	adac_unpack_job job = MakeJob(DeviceDesc(), start_row, scan_count, 0);
+	Check(adac_unpack_jobs(pool.ctx, (int)type, &job, 1, pool.d_arena, d_out), "adac_unpack_jobs");
+	uint8_t *bounce = pool.PinnedStaging(scan_count * type_size);
+	Check(adac_memcpy_d2h(pool.ctx, bounce, d_out, scan_count * type_size), "adac_memcpy_d2h");
+	std::memcpy(target, bounce, scan_count * type_size);
+}
+
+CacheEntry *ColumnSegment::PinDecoded(bool may_schedule) {
+	// bit_compression_lock of this segment is held; the segment is packed on the device
+	SegmentPool &p = pool;
+	const size_t my_bytes = count * type_size;
+	if (!p.cache_capacity || my_bytes == 0 || my_bytes > SegmentPool::kCacheSlotBytes) return nullptr;
+	struct Item {
+		CacheEntry *e;
+		adac_unpack_job job;
+	};
+	std::vector<Item> items;
+	std::shared_ptr<DecodeBatch> batch;
+	CacheEntry *mine = nullptr;
+	{
+		std::lock_guard<std::mutex> chain(db.chain_lock); // the hint walk; keeps the followers from being destroyed
+		std::lock_guard<std::mutex> cl(p.cache_lock);
+		auto it = p.cache.find(segment_id);
+		if (it != p.cache.end() && it->second->version != version) {
+			p.CacheDropLocked(segment_id); // decoded from a representation that is gone
+			it = p.cache.end();
+		}
+		bool walk = false;
+		if (it != p.cache.end()) {
+			mine = it->second;
+			mine->pins++;
+			p.lru.splice(p.lru.begin(), p.lru, mine->lru);
+			p.cache_hits++;
+			if (mine->trigger && may_schedule) {
+				mine->trigger = false;
+				walk = true;
+			}
+		} else {
+			p.cache_misses++;
+			if (!may_schedule) return nullptr;
+			walk = true;
+		}
+		if (walk) {
+			// this segment (on a miss) and the next ones of the column that live in this pool, decoded as ONE batch:
+			// one launch, one copy down per run of adjacent blocks.  The first prefetched segment is the trigger for
+			// the batch after this one, so a sequential scan always has about one batch in flight ahead of it.
+			const uint32_t B = p.prefetch_segments;
+			const uint32_t window = 2 * B * (uint32_t)db.pools.size(); // consecutive segments alternate pools
+			uint32_t looked = 0;
+			bool first_prefetched = true;
+			for (ColumnSegment *s = this; s && looked < window && items.size() < B; s = s->next_hint, looked++) {
+				if (s == this) {
+					if (mine) continue;
+				} else if (&s->pool != &p || s->type_size != type_size) {
+					continue;
+				}
+				std::unique_lock<std::mutex> sl;
+				if (s != this) {
+					// try only: a flip in progress holds that lock and may be waiting for one of ours
+					sl = std::unique_lock<std::mutex>(s->bit_compression_lock, std::try_to_lock);
+					if (!sl.owns_lock()) continue;
+					if (!s->function || s->function->type != CompressionType::COMPRESSION_SUCCINCT || !s->packed_on_device ||
+					    s->count == 0 || s->count * s->type_size > SegmentPool::kCacheSlotBytes) {
+						continue;
+					}
+					auto have = p.cache.find(s->segment_id);
+					if (have != p.cache.end()) {
+						if (have->second->version == s->version) continue;
+						p.CacheDropLocked(s->segment_id);
+					}
+				}
+				CacheEntry *e = p.CacheInsertLocked(s->segment_id, s->version, s->count * s->type_size);
+				if (!e) break; // every block is pinned or in flight
+				if (!batch) batch = std::make_shared<DecodeBatch>();
+				e->batch = batch;
+				if (s == this) {
+					e->pins = 1;
+					mine = e;
+				} else {
+					if (first_prefetched) e->trigger = true;
+					first_prefetched = false;
+					p.cache_prefetched++;
+				}
+				items.push_back(Item {e, MakeJob(s->DeviceDesc(), 0, s->count, 0)});
+			}
+		}
+	}
+	if (!items.empty()) {
+		// enqueue outside the cache lock: other consumers keep hitting while this thread talks to the device
+		std::sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.e->slot < b.e->slot; });
+		std::vector<adac_unpack_job> jobs(items.size());
+		const uint64_t slot_elems = SegmentPool::kCacheSlotBytes / type_size;
+		for (size_t i = 0; i < items.size(); i++) {
+			jobs[i] = items[i].job;
+			jobs[i].out_off = i * slot_elems; // staging mirrors the slab: adjacent slots are adjacent in staging
+		}
+		std::unique_lock<std::mutex> held;
+		ScanLane &lane = p.AcquireLane(held);
+		adac_status st = adac_unpack_jobs(lane.ctx, (int)type, jobs.data(), jobs.size(), p.d_arena, lane.d_stage);
+		for (size_t i = 0; st == ADAC_OK && i < items.size();) {
+			size_t j = i + 1;
+			while (j < items.size() && items[j].e->slot == items[j - 1].e->slot + 1) j++;
+			// whole slots of the run but the last, whose tail past its rows is not needed
+			const size_t bytes = (j - 1 - i) * SegmentPool::kCacheSlotBytes + items[j - 1].e->bytes;
+			st = adac_memcpy_d2h_async(lane.ctx, items[i].e->data,
+			                           static_cast<uint8_t *>(lane.d_stage) + i * SegmentPool::kCacheSlotBytes, bytes);
+			i = j;
+		}
+		adac_event *ev = nullptr;
+		if (st == ADAC_OK) st = adac_event_record(lane.ctx, &ev);
+		held.unlock();
+		batch->Publish(ev, st == ADAC_OK);
+		p.cache_batches++;
+		if (st != ADAC_OK) {
+			std::lock_guard<std::mutex> cl(p.cache_lock);
+			for (auto &it : items) {
+				if (!it.e->dropped) p.CacheDropLocked(it.e->key); // a pinned one (mine) becomes a zombie until unpinned
+			}
+		}
+	}
+	if (!mine) return nullptr;
+	if (!mine->batch->Wait()) {
+		p.CacheUnpin(mine);
+		return nullptr;
+	}
+	return mine;
+}
+
+void ColumnSegment::ScanRows(ColumnScanState *state, idx_t start_row, idx_t scan_count, data_ptr_t target) {
 	if (start_row > count || scan_count > count - start_row) throw InternalException("scan beyond the segment");
 	if (scan_count == 0) return;
-	std::lock_guard<std::mutex> g(bit_compression_lock);
+	std::unique_lock<std::mutex> g(bit_compression_lock);
 	if (function->type == CompressionType::COMPRESSION_SUCCINCT && packed_on_device) {
-		std::lock_guard<std::mutex> pg(db.pool.lock);
-		if (db.pool.cache_capacity) {
-			// vector-serving cache: decode the WHOLE segment once, serve this and the following vectors by memcpy
-			auto found = db.pool.cache.find(this);
-			const bool was_prefetched = found != db.pool.cache.end() && found->second.pending;
-			const uint8_t *hit = db.pool.CacheLookup(this); // waits for a prefetch in flight
-			bool fresh = was_prefetched;
-			if (!hit) {
-				uint8_t *block = db.pool.CacheInsert(this, count * type_size);
-				if (block) {
-					void *d_all = db.pool.Staging(count * type_size);
-					Check(adac_unpack_range(LayoutOf(device_layout), db.pool.d_arena, layout_index, 0, count, d_all, 0),
-					      "adac_unpack_range");
-					Check(adac_memcpy_d2h(db.pool.ctx, block, d_all, count * type_size), "adac_memcpy_d2h");
-					for (auto &kv : db.pool.cache) kv.second.pending = false; // synchronous copy on the one stream
-					hit = block;
-					fresh = true;
+		if (pool.cache_capacity) {
+			// vector-serving cache: the WHOLE segment is decoded once (together with the next few of the column, ahead
+			// of the consumer); this and the following vectors are memcpys out of the block the scan state pins
+			SuccinctScanState *ss = state ? dynamic_cast<SuccinctScanState *>(state->scan_state.get()) : nullptr;
+			if (ss && ss->pin && (ss->segment_id != segment_id || ss->version != version)) ss->Release();
+			CacheEntry *e = ss ? ss->pin : nullptr;
+			if (!e) {
+				e = PinDecoded(/*may_schedule=*/state != nullptr); // a one-off read (fetch_row) only uses what is there
+				if (e && ss) {
+					ss->pool = &pool;
+					ss->pin = e;
+					ss->segment_id = segment_id;
+					ss->version = version;
 				}
 			}
-			if (hit) {
-				// first touch of this segment's image: once the rows are out, start the next segment's decode + copy,
-				// so that it runs while the consumer reads this one (a sequential scan then waits for PCIe once)
-				std::memcpy(target, hit + start_row * type_size, scan_count * type_size);
-				if (fresh && next_hint) next_hint->PrefetchIntoCache(this);
+			if (e) {
+				g.unlock(); // the pin keeps the block; a flip from here on is seen by the next call's version check
+				std::memcpy(target, e->data + start_row * type_size, scan_count * type_size);
+				if (!ss) pool.CacheUnpin(e);
 				return;
 			}
 		}
-		void *d_out = db.pool.Staging(scan_count * type_size);
-		Check(adac_unpack_range(LayoutOf(device_layout), db.pool.d_arena, layout_index, start_row, scan_count, d_out, 0),
-		      "adac_unpack_range");
-		// the engine's result vector is pageable memory: copy down into the page-locked staging block (a direct
-		// DMA) and move the few KiB from there, instead of letting the runtime stage the copy itself
-		uint8_t *bounce = db.pool.PinnedStaging(scan_count * type_size);
-		Check(adac_memcpy_d2h(db.pool.ctx, bounce, d_out, scan_count * type_size), "adac_memcpy_d2h");
-		std::memcpy(target, bounce, scan_count * type_size);
+		DecodeRowsDirect(start_row, scan_count, target);
 	} else {
 		// unpacked slots / uncompressed block: the bytes ARE the values (no min add: SURVEY.md §8a (iii))
 		std::memcpy(target, raw.data() + start_row * type_size, scan_count * type_size);
 	}
-}
-
-void ColumnSegment::PrefetchIntoCache(const ColumnSegment *reader) {
-	// called with pool.lock held by a scan of the PREVIOUS segment (`reader`).  This segment's state is read under
-	// its own lock, taken with try_lock only: a flip in progress on it holds that lock and may be waiting for
-	// pool.lock.
-	std::unique_lock<std::mutex> g(bit_compression_lock, std::try_to_lock);
-	if (!g.owns_lock()) return;
-	if (!function || function->type != CompressionType::COMPRESSION_SUCCINCT || !packed_on_device || count == 0) return;
-	auto &pool = db.pool;
-	if (pool.cache.count(this)) return;
-	for (auto &kv : pool.cache) {
-		if (kv.second.pending) return; // one prefetch in flight at a time (one staging buffer)
-	}
-	const size_t bytes = count * type_size;
-	const bool slotted = pool.cache_slab && bytes <= SegmentPool::kCacheSlotBytes;
-	const size_t charge = slotted ? SegmentPool::kCacheSlotBytes : bytes;
-	const bool evicts = pool.cache_used + charge > pool.cache_capacity || (slotted && pool.cache_free_slots.empty());
-	// never at the reader's expense: its block was touched last, so with two or more entries the victim is another
-	if (evicts && (pool.cache.size() < 2 || !pool.cache.count(reader))) return;
-	uint8_t *block = pool.CacheInsert(this, bytes);
-	if (!block) return;
-	void *d_all = pool.PrefetchStaging(bytes);
-	Check(adac_unpack_range(LayoutOf(device_layout), pool.d_arena, layout_index, 0, count, d_all, 0), "adac_unpack_range");
-	Check(adac_memcpy_d2h_async(pool.ctx, block, d_all, bytes), "adac_memcpy_d2h_async");
-	pool.cache[this].pending = true;
-	pool.cache_misses++; // a device decode of this segment, as a miss would have been; the look-up will be a hit
-	pool.cache_prefetches++;
 }
 
 idx_t ColumnSegment::AppendRows(UnifiedVectorFormat &data, idx_t offset, idx_t append_count) {
@@ -572,17 +826,21 @@ idx_t ColumnSegment::AppendRows(UnifiedVectorFormat &data, idx_t offset, idx_t a
 	const bool track_validity = function->type == CompressionType::COMPRESSION_SUCCINCT;
 	const uint64_t null_bits = NullBits(type, type_size);
 	if (track_validity && validity.empty()) validity.assign((max_tuple_count + 63) / 64 + 1, ~0ull);
-	for (idx_t i = 0; i < copy_count; i++) {
-		idx_t source_idx = data.sel ? data.sel[offset + i] : offset + i;
-		idx_t target_idx = count + i;
-		bool valid = !data.validity || ((data.validity[source_idx >> 6] >> (source_idx & 63)) & 1);
-		if (valid) {
-			std::memcpy(raw.data() + target_idx * type_size, data.data + source_idx * type_size, type_size);
-		} else {
-			std::memcpy(raw.data() + target_idx * type_size, &null_bits, type_size); // NullValue<T>()
-			if (track_validity) {
-				validity[target_idx >> 6] &= ~(1ull << (target_idx & 63));
-				any_null = true;
+	if (!data.sel && !data.validity) {
+		std::memcpy(raw.data() + count * type_size, data.data + offset * type_size, copy_count * type_size);
+	} else {
+		for (idx_t i = 0; i < copy_count; i++) {
+			idx_t source_idx = data.sel ? data.sel[offset + i] : offset + i;
+			idx_t target_idx = count + i;
+			bool valid = !data.validity || ((data.validity[source_idx >> 6] >> (source_idx & 63)) & 1);
+			if (valid) {
+				std::memcpy(raw.data() + target_idx * type_size, data.data + source_idx * type_size, type_size);
+			} else {
+				std::memcpy(raw.data() + target_idx * type_size, &null_bits, type_size); // NullValue<T>()
+				if (track_validity) {
+					validity[target_idx >> 6] &= ~(1ull << (target_idx & 63));
+					any_null = true;
+				}
 			}
 		}
 	}
@@ -594,7 +852,7 @@ idx_t ColumnSegment::Append(UnifiedVectorFormat &append_data, idx_t offset, idx_
 	// column_segment.cpp:247-271.  The whole append is one flip-free section: the background policy thread must
 	// not compact the segment between the Uncompact below and the write into the unpacked image (in the
 	// reference that window is open: its TSan suppressions cover it)
-	std::lock_guard<std::recursive_mutex> flips(db.flip_lock);
+	std::lock_guard<std::recursive_mutex> flips(pool.flip_lock);
 	bool uncompacted = false;
 	if (IsBitCompressed()) {
 		Uncompact();
@@ -622,60 +880,85 @@ void ColumnSegment::Compact() {
 	CompactMany(db, one);
 }
 
-void ColumnSegment::CompactMany(DatabaseInstance &db, const std::vector<ColumnSegment *> &segments) {
-	// Batched ColumnSegment::Compact (column_segment.cpp:273-322): per (type, rule) group one upload, one
-	// adac_analyze, the width decision on the host from the downloaded min/max, one adac_pack.
-	std::lock_guard<std::recursive_mutex> flips(db.flip_lock);
-	std::map<std::pair<uint8_t, int>, std::vector<ColumnSegment *>> groups;
-	for (auto *s : segments) {
-		if (!s->NeedsCompaction()) continue;
-		int rule = s->function->type == CompressionType::COMPRESSION_SUCCINCT ? ADAC_RULE_APPEND : ADAC_RULE_RECOMPACT;
-		groups[{(uint8_t)s->type, rule}].push_back(s);
+// Frees the arena blocks a batch took if the batch does not reach the point where its segments own them.
+struct ArenaRollback {
+	SegmentPool &pool;
+	std::vector<std::pair<uint64_t, uint64_t>> blocks; // word_off, words
+	bool armed = true;
+	explicit ArenaRollback(SegmentPool &p) : pool(p) {
 	}
-	const bool padded = db.config.succinct_padded_to_next_byte_enabled;
-	for (auto &g : groups) {
-		PhaseTrace trace;
-		const int ptype = g.first.first;
-		const int rule = g.first.second;
-		auto &segs = g.second;
-		const idx_t ts = adac_type_size(ptype);
-		const idx_t per16 = 16 / ts;
-		std::vector<uint32_t> counts(segs.size());
-		std::vector<uint64_t> offs(segs.size());
-		uint64_t span = 0;
-		bool any_null = false;
-		for (size_t i = 0; i < segs.size(); i++) {
-			counts[i] = (uint32_t)segs[i]->count;
-			offs[i] = span;
-			span += (segs[i]->count + per16 - 1) / per16 * per16; // keep every segment 16-byte aligned
-			any_null |= (rule == ADAC_RULE_APPEND && segs[i]->any_null);
+	~ArenaRollback() {
+		if (armed) {
+			for (auto &b : blocks) pool.Free(b.first, b.second);
 		}
-		const size_t host_bytes = span * ts + 16;
-		std::vector<uint64_t> vmask;
-		if (any_null) vmask.assign(span / 64 + 2, ~0ull);
-		if (any_null) {
-			for (size_t i = 0; i < segs.size(); i++) {
-				if (!segs[i]->any_null) continue;
-				for (idx_t r = 0; r < segs[i]->count; r++) {
-					if (!((segs[i]->validity[r >> 6] >> (r & 63)) & 1)) {
-						uint64_t e = offs[i] + r;
-						vmask[e >> 6] &= ~(1ull << (e & 63));
-					}
+	}
+};
+
+void ColumnSegment::CompactMany(DatabaseInstance &db, const std::vector<ColumnSegment *> &segments) {
+	// Batched ColumnSegment::Compact (column_segment.cpp:273-322): per (pool, type, rule) group one upload, one
+	// adac_analyze, the width decision on the host from the downloaded min/max, one adac_pack.
+	std::map<std::tuple<int, uint8_t, int>, std::vector<ColumnSegment *>> groups;
+	for (auto *s : segments) {
+		int rule = s->function->type == CompressionType::COMPRESSION_SUCCINCT ? ADAC_RULE_APPEND : ADAC_RULE_RECOMPACT;
+		groups[std::make_tuple(s->pool.index, (uint8_t)s->type, rule)].push_back(s);
+	}
+	for (auto &g : groups) {
+		SegmentPool &pool = *db.pools[std::get<0>(g.first)];
+		std::lock_guard<std::recursive_mutex> flips(pool.flip_lock);
+		std::vector<ColumnSegment *> todo;
+		for (auto *s : g.second) {
+			// decided under the flip lock; the rule is re-read there too (an Uncompact may have come in between)
+			const int rule = s->function->type == CompressionType::COMPRESSION_SUCCINCT ? ADAC_RULE_APPEND : ADAC_RULE_RECOMPACT;
+			if (s->NeedsCompaction() && rule == std::get<2>(g.first)) todo.push_back(s);
+		}
+		if (!todo.empty()) CompactGroup(db, pool, std::get<1>(g.first), std::get<2>(g.first), todo);
+	}
+}
+
+void ColumnSegment::CompactGroup(DatabaseInstance &db, SegmentPool &pool, int ptype, int rule,
+                                 const std::vector<ColumnSegment *> &segs) {
+	// pool.flip_lock is held by the caller
+	PhaseTrace trace;
+	const bool padded = db.config.succinct_padded_to_next_byte_enabled;
+	const idx_t ts = adac_type_size(ptype);
+	const idx_t per16 = 16 / ts;
+	std::vector<uint32_t> counts(segs.size());
+	std::vector<uint64_t> offs(segs.size());
+	uint64_t span = 0;
+	bool any_null = false;
+	for (size_t i = 0; i < segs.size(); i++) {
+		counts[i] = (uint32_t)segs[i]->count;
+		offs[i] = span;
+		span += (segs[i]->count + per16 - 1) / per16 * per16; // keep every segment 16-byte aligned
+		any_null |= (rule == ADAC_RULE_APPEND && segs[i]->any_null);
+	}
+	const size_t host_bytes = span * ts + 16;
+	std::vector<uint64_t> vmask;
+	if (any_null) {
+		vmask.assign(span / 64 + 2, ~0ull);
+		for (size_t i = 0; i < segs.size(); i++) {
+			if (!segs[i]->any_null) continue;
+			for (idx_t r = 0; r < segs[i]->count; r++) {
+				if (!((segs[i]->validity[r >> 6] >> (r & 63)) & 1)) {
+					uint64_t e = offs[i] + r;
+					vmask[e >> 6] &= ~(1ull << (e & 63));
 				}
 			}
 		}
-		std::vector<uint64_t> mm(2 * segs.size());
-		std::vector<adac_segment_desc> descs;
-		std::vector<size_t> pidx;
-		std::vector<uint8_t> widths(segs.size());
-		std::shared_ptr<LayoutHandle> handle;
-		{ // device work under the pool lock; representation flips (bit_compression_lock) after it is released
-		std::lock_guard<std::mutex> pg(db.pool.lock);
-		adac_ctx *ctx = db.pool.ctx;
+	}
+	std::vector<uint64_t> mm(2 * segs.size());
+	std::vector<adac_segment_desc> descs; // of the segments that get packed, in order
+	std::vector<size_t> pidx;             // their indices in segs
+	std::vector<uint8_t> widths(segs.size());
+	std::vector<char> skipped(segs.size(), 0); // no arena space: stays as it is (still needs compaction)
+	ArenaRollback rollback(pool);
+	{ // device work under the pool lock; representation flips (bit_compression_lock) after it is released
+		std::lock_guard<std::mutex> pg(pool.lock);
+		adac_ctx *ctx = pool.ctx;
 		trace.mark("prep");
 		// gather the segments' rows into page-locked staging (a few host threads for big batches: the gather,
 		// not PCIe, bounds a re-compaction round) and upload them with one copy at PCIe rate
-		uint8_t *host = db.pool.PinnedStaging(host_bytes);
+		uint8_t *host = pool.PinnedStaging(host_bytes);
 		trace.mark("pinned_alloc");
 		{
 			auto gather = [&](size_t lo, size_t hi) {
@@ -699,21 +982,21 @@ void ColumnSegment::CompactMany(DatabaseInstance &db, const std::vector<ColumnSe
 			}
 		}
 		trace.mark("gather");
-		void *d_vals = db.pool.Staging(host_bytes);
+		void *d_vals = pool.Staging(host_bytes);
 		trace.mark("dev_alloc");
 		Check(adac_memcpy_h2d(ctx, d_vals, host, host_bytes), "upload rows");
 		trace.mark("h2d");
 		uint64_t *d_valid = nullptr;
 		if (any_null) {
-			d_valid = static_cast<uint64_t *>(db.pool.Staging2(vmask.size() * 8));
+			d_valid = static_cast<uint64_t *>(pool.Staging2(vmask.size() * 8));
 			Check(adac_memcpy_h2d(ctx, d_valid, vmask.data(), vmask.size() * 8), "upload validity");
 		}
-		adac_layout *probe = nullptr;
-		Check(adac_layout_create(ctx, ptype, counts.data(), offs.data(), segs.size(), &probe), "adac_layout_create");
-		adac_status st = adac_analyze(probe, d_vals, d_valid, rule);
-		if (st == ADAC_OK) st = adac_layout_get_minmax(probe, mm.data());
-		adac_layout_destroy(probe);
-		Check(st, "adac_analyze");
+		{
+			LayoutGuard probe;
+			Check(adac_layout_create(ctx, ptype, counts.data(), offs.data(), segs.size(), &probe.layout), "adac_layout_create");
+			Check(adac_analyze(probe.layout, d_vals, d_valid, rule), "adac_analyze");
+			Check(adac_layout_get_minmax(probe.layout, mm.data()), "adac_layout_get_minmax");
+		}
 		trace.mark("analyze");
 		// width decision (column_segment.cpp:351-363 / :404-420) and arena placement
 		std::vector<uint32_t> pcounts;
@@ -723,7 +1006,14 @@ void ColumnSegment::CompactMany(DatabaseInstance &db, const std::vector<ColumnSe
 			widths[i] = w;
 			if (8 * ts > w) {
 				adac_segment_desc d;
-				d.word_off = db.pool.Allocate(adac_arena_words(counts[i], w));
+				const uint64_t need = adac_arena_words(counts[i], w);
+				if (!pool.TryAllocate(need, d.word_off)) {
+					// the arena is full: the segment keeps its unpacked form and is tried again by the next round
+					skipped[i] = 1;
+					pool.exhausted_events++;
+					continue;
+				}
+				rollback.blocks.emplace_back(d.word_off, need);
 				d.val_off = offs[i];
 				d.min = adac_stored_min(mm[2 * i], mm[2 * i + 1], w); // all-ones segments: see adacodec.h
 				d.count = counts[i];
@@ -737,40 +1027,37 @@ void ColumnSegment::CompactMany(DatabaseInstance &db, const std::vector<ColumnSe
 			}
 		}
 		if (!descs.empty()) {
-			handle = std::make_shared<LayoutHandle>();
-			Check(adac_layout_create(ctx, ptype, pcounts.data(), poffs.data(), descs.size(), &handle->layout),
+			LayoutGuard packer;
+			Check(adac_layout_create(ctx, ptype, pcounts.data(), poffs.data(), descs.size(), &packer.layout),
 			      "adac_layout_create");
-			Check(adac_layout_set_descs(handle->layout, descs.data()), "adac_layout_set_descs");
+			Check(adac_layout_set_descs(packer.layout, descs.data()), "adac_layout_set_descs");
 			trace.mark("alloc+layout");
-			Check(adac_pack(handle->layout, d_vals, d_valid, db.pool.d_arena), "adac_pack");
+			Check(adac_pack(packer.layout, d_vals, d_valid, pool.d_arena), "adac_pack");
 			Check(adac_ctx_sync(ctx), "adac_ctx_sync");
 			trace.mark("pack");
 		}
-		} // pool lock released
-		size_t p = 0;
-		// the unpacked images of a big batch go back to the OS off the critical path: unmapping a 256 KiB block
-		// costs ~18 us, 6.5 ms for the 360 segments of a first policy round
-		std::vector<std::vector<uint8_t>> graveyard;
-		if (segs.size() > 8) graveyard.reserve(segs.size());
-		for (size_t i = 0; i < segs.size(); i++) {
-			bool packed = p < pidx.size() && pidx[p] == i;
-			if (packed) {
-				segs[i]->device_layout = handle;
-				segs[i]->layout_index = p;
-			}
-			segs[i]->FinishCompaction(packed, widths[i], mm[2 * i], mm[2 * i + 1], rule,
-			                          packed ? descs[p].word_off : 0, segs.size() > 8 ? &graveyard : nullptr);
-			if (packed) p++;
-		}
-		if (!graveyard.empty()) {
-			std::thread([g = std::move(graveyard)]() mutable { g.clear(); }).detach();
-		}
-		trace.mark("finish");
+	} // pool lock released
+	rollback.armed = false; // from here on the segments own their blocks
+	size_t p = 0;
+	// the unpacked images of a big batch go back to the OS off the critical path: unmapping a 256 KiB block
+	// costs ~18 us, 6.5 ms for the 360 segments of a first policy round
+	std::vector<std::vector<uint8_t>> graveyard;
+	if (segs.size() > 8) graveyard.reserve(segs.size());
+	for (size_t i = 0; i < segs.size(); i++) {
+		if (skipped[i]) continue;
+		bool packed = p < pidx.size() && pidx[p] == i;
+		segs[i]->FinishCompaction(packed, widths[i], mm[2 * i], mm[2 * i + 1], rule, packed ? descs[p].word_off : 0,
+		                          packed ? descs[p].min : UINT64_MAX, segs.size() > 8 ? &graveyard : nullptr);
+		if (packed) p++;
 	}
+	if (!graveyard.empty()) {
+		std::thread([g = std::move(graveyard)]() mutable { g.clear(); }).detach();
+	}
+	trace.mark("finish");
 }
 
 void ColumnSegment::FinishCompaction(bool packed, uint8_t width, uint64_t mn, uint64_t mx, int rule, uint64_t off,
-                                     std::vector<std::vector<uint8_t>> *graveyard) {
+                                     uint64_t stored_min, std::vector<std::vector<uint8_t>> *graveyard) {
 	std::lock_guard<std::mutex> g(bit_compression_lock);
 	const idx_t before = GetDataSize();
 	if (rule == ADAC_RULE_APPEND) {
@@ -790,6 +1077,7 @@ void ColumnSegment::FinishCompaction(bool packed, uint8_t width, uint64_t mn, ui
 		packed_on_device = true;
 		word_off = off;
 		arena_words = adac_arena_words(count, width);
+		device_min = stored_min;
 		// the unpacked image is gone, as after SDSL's realloc shrink
 		if (graveyard) {
 			graveyard->emplace_back(std::move(raw));
@@ -802,36 +1090,206 @@ void ColumnSegment::FinishCompaction(bool packed, uint8_t width, uint64_t mn, ui
 	any_null = false;
 	function = db.GetCompressionFunction(CompressionType::COMPRESSION_SUCCINCT, type);
 	compacted = true;
+	version++;
 	db.data_size += (int64_t)GetDataSize() - (int64_t)before;
 }
 
 void ColumnSegment::Uncompact() {
 	// column_segment.cpp:324-346 + UncompressSuccinct :458-506
-	std::lock_guard<std::recursive_mutex> flips(db.flip_lock);
+	std::lock_guard<std::recursive_mutex> flips(pool.flip_lock);
 	if (!compacted || !function || function->type != CompressionType::COMPRESSION_SUCCINCT) return;
 	std::lock_guard<std::mutex> g(bit_compression_lock);
 	const idx_t compressed_size = adac_size_in_bytes(vec_slots, vec_width);
 	if (packed_on_device) {
 		raw.assign(segment_size, 0);
-		std::lock_guard<std::mutex> pg(db.pool.lock);
 		if (count) {
-			void *d_out = db.pool.Staging(count * type_size);
-			Check(adac_unpack_range(LayoutOf(device_layout), db.pool.d_arena, layout_index, 0, count, d_out, 0),
-			      "adac_unpack_range");
-			uint8_t *bounce = db.pool.PinnedStaging(count * type_size);
-			Check(adac_memcpy_d2h(db.pool.ctx, bounce, d_out, count * type_size), "adac_memcpy_d2h");
+			std::lock_guard<std::mutex> pg(pool.lock);
+			void *d_out = pool.Staging(count * type_size);
+			adac_unpack_job job = MakeJob(DeviceDesc(), 0, count, 0);
+			Check(adac_unpack_jobs(pool.ctx, (int)type, &job, 1, pool.d_arena, d_out), "adac_unpack_jobs");
+			uint8_t *bounce = pool.PinnedStaging(count * type_size);
+			Check(adac_memcpy_d2h(pool.ctx, bounce, d_out, count * type_size), "adac_memcpy_d2h");
 			std::memcpy(raw.data(), bounce, count * type_size);
 		}
-		db.pool.Free(word_off, arena_words);
-		db.pool.CacheDrop(this);
+		pool.Free(word_off, arena_words);
+		pool.CacheDrop(segment_id);
 		packed_on_device = false;
-		device_layout.reset();
 	}
 	function = db.GetCompressionFunction(CompressionType::COMPRESSION_UNCOMPRESSED, type);
 	compacted = false;
 	vec_slots = 0; // succinct_vec.resize(0)
-	force_reinitializing_scan_state = true;
+	version++;     // force_reinitializing_scan_state = true: scan states re-pin on their next call
+	segment_type = ColumnSegmentType::TRANSIENT;
 	db.data_size += (int64_t)segment_size - (int64_t)compressed_size;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistence
+// ------------------------------------------------------------------------------------------------
+
+void ColumnSegment::ConvertToPersistent(std::vector<uint8_t> &image) {
+	std::vector<ColumnSegment *> one {this};
+	std::vector<std::vector<uint8_t>> images;
+	ConvertManyToPersistent(db, one, images);
+	image = std::move(images[0]);
+}
+
+void ColumnSegment::ConvertManyToPersistent(DatabaseInstance &db, const std::vector<ColumnSegment *> &segments,
+                                            std::vector<std::vector<uint8_t>> &images) {
+	images.assign(segments.size(), std::vector<uint8_t>());
+	CompactMany(db, segments); // a segment that was never scanned or filled is still in its append form
+	std::map<std::pair<int, uint8_t>, std::vector<size_t>> groups; // (pool, type) -> indices into segments
+	for (size_t i = 0; i < segments.size(); i++) {
+		groups[{segments[i]->pool.index, (uint8_t)segments[i]->type}].push_back(i);
+	}
+	for (auto &g : groups) {
+		SegmentPool &pool = *db.pools[g.first.first];
+		const int ptype = g.first.second;
+		std::lock_guard<std::recursive_mutex> flips(pool.flip_lock); // no flip while the images are taken
+		std::vector<adac_segment_desc> descs;
+		std::vector<uint64_t> offs;
+		std::vector<size_t> on_device;
+		uint64_t total = 0;
+		for (size_t i : g.second) {
+			ColumnSegment &s = *segments[i];
+			std::lock_guard<std::mutex> sl(s.bit_compression_lock);
+			const bool empty = s.count == 0; // e.g. the last segment FinalizeCompress flushes: nothing to compact
+			if (!empty && (!s.compacted || s.function->type != CompressionType::COMPRESSION_SUCCINCT)) {
+				throw InternalException("ConvertToPersistent: the segment is not in its succinct form");
+			}
+			if (!empty && s.packed_on_device) {
+				descs.push_back(s.DeviceDesc());
+				offs.push_back(total);
+				total += adac_block_stride(s.count, s.vec_width);
+				on_device.push_back(i);
+			} else {
+				// slots at the type's own width (nothing to gain from packing): the image is built from the host
+				// block — bytes only, no arithmetic
+				adac_segment_desc d;
+				std::memset(&d, 0, sizeof d);
+				d.min = s.min_factor;
+				d.count = (uint32_t)s.count;
+				d.width = (uint8_t)(8 * s.type_size);
+				d.flags = 0;
+				std::vector<uint64_t> words(adac_packed_words(s.count, d.width) + 1, 0);
+				std::memcpy(words.data(), s.raw.data(), s.count * s.type_size);
+				images[i].resize(adac_block_bytes(s.count, d.width));
+				if (adac_block_write(&d, ptype, words.data(), images[i].data(), images[i].size()) != images[i].size()) {
+					throw InternalException("adac_block_write failed");
+				}
+			}
+			s.segment_type = ColumnSegmentType::PERSISTENT;
+		}
+		if (on_device.empty()) continue;
+		std::lock_guard<std::mutex> pg(pool.lock);
+		void *d_blocks = pool.Staging(total);
+		Check(adac_blocks_write(pool.ctx, ptype, descs.data(), offs.data(), descs.size(), pool.d_arena, d_blocks),
+		      "adac_blocks_write");
+		uint8_t *host = pool.PinnedStaging(total);
+		Check(adac_memcpy_d2h(pool.ctx, host, d_blocks, total), "adac_memcpy_d2h(blocks)");
+		for (size_t k = 0; k < on_device.size(); k++) {
+			const size_t bytes = adac_block_bytes(descs[k].count, descs[k].width);
+			images[on_device[k]].assign(host + offs[k], host + offs[k] + bytes);
+		}
+	}
+}
+
+std::vector<std::unique_ptr<ColumnSegment>>
+ColumnSegment::CreatePersistentSegments(DatabaseInstance &db,
+                                        const std::vector<std::pair<const uint8_t *, size_t>> &images,
+                                        const std::vector<idx_t> &starts) {
+	if (images.size() != starts.size()) throw InternalException("CreatePersistentSegments: one start row per image");
+	std::vector<std::unique_ptr<ColumnSegment>> out(images.size());
+	std::vector<adac_segment_desc> headers(images.size());
+	std::vector<int> types(images.size());
+	for (size_t i = 0; i < images.size(); i++) {
+		Check(adac_block_peek(images[i].first, images[i].second, &headers[i], &types[i]), "adac_block_peek");
+		const PhysicalType type = (PhysicalType)types[i];
+		const idx_t ts = adac_type_size(types[i]);
+		// a segment of the loaded size: Storage::BLOCK_SIZE unless the image holds more rows than that
+		const idx_t seg_size = std::max<idx_t>(BLOCK_SIZE, (idx_t)headers[i].count * ts);
+		auto fn = db.GetCompressionFunction(CompressionType::COMPRESSION_SUCCINCT, type);
+		out[i].reset(new ColumnSegment(db, type, starts[i], seg_size, fn, true,
+		                               db.config.adaptive_succinct_compression_enabled));
+	}
+	// per (pool, type): place the packed ones in the arena, one upload of their images, one device pass
+	std::map<std::pair<int, uint8_t>, std::vector<size_t>> groups;
+	for (size_t i = 0; i < images.size(); i++) groups[{out[i]->pool.index, (uint8_t)out[i]->type}].push_back(i);
+	for (auto &g : groups) {
+		SegmentPool &pool = *db.pools[g.first.first];
+		const int ptype = g.first.second;
+		std::lock_guard<std::recursive_mutex> flips(pool.flip_lock);
+		std::vector<adac_segment_desc> descs;
+		std::vector<uint64_t> offs;
+		std::vector<size_t> idx;
+		uint64_t total = 0;
+		ArenaRollback rollback(pool);
+		for (size_t i : g.second) {
+			const adac_segment_desc &h = headers[i];
+			if (!(h.flags & ADAC_SEG_PACKED)) continue;
+			adac_segment_desc d = h;
+			const uint64_t need = adac_arena_words(h.count, h.width);
+			if (!pool.TryAllocate(need, d.word_off)) throw InternalException("adacodec: segment pool arena exhausted");
+			rollback.blocks.emplace_back(d.word_off, need);
+			descs.push_back(d);
+			offs.push_back(total);
+			total += adac_block_stride(h.count, h.width);
+			idx.push_back(i);
+		}
+		if (!descs.empty()) {
+			std::lock_guard<std::mutex> pg(pool.lock);
+			uint8_t *host = pool.PinnedStaging(total);
+			for (size_t k = 0; k < idx.size(); k++) {
+				const size_t stride = adac_block_stride(descs[k].count, descs[k].width);
+				const size_t have = std::min(images[idx[k]].second, stride);
+				std::memcpy(host + offs[k], images[idx[k]].first, have);
+				std::memset(host + offs[k] + have, 0, stride - have);
+			}
+			void *d_blocks = pool.Staging(total);
+			Check(adac_memcpy_h2d(pool.ctx, d_blocks, host, total), "adac_memcpy_h2d(blocks)");
+			Check(adac_blocks_read(pool.ctx, ptype, descs.data(), offs.data(), descs.size(), d_blocks, pool.d_arena),
+			      "adac_blocks_read");
+		}
+		rollback.armed = false;
+		size_t k = 0;
+		for (size_t i : g.second) {
+			ColumnSegment &s = *out[i];
+			const adac_segment_desc &h = headers[i];
+			std::lock_guard<std::mutex> sl(s.bit_compression_lock);
+			const idx_t before = s.GetDataSize();
+			s.count = h.count;
+			s.num_elements = h.count;
+			s.segment_type = ColumnSegmentType::PERSISTENT;
+			s.appended_via_succinct = true;
+			s.compacted = true;
+			s.vec_width = h.width;
+			if (h.flags & ADAC_SEG_PACKED) {
+				s.vec_slots = h.count;
+				s.packed_on_device = true;
+				s.word_off = descs[k].word_off;
+				s.arena_words = adac_arena_words(h.count, h.width);
+				s.device_min = h.min;
+				s.min_factor = h.min;
+				// the image does not carry max_factor; the tightest bound the width allows stands in for it
+				s.max_factor = h.width >= 64 ? UINT64_MAX : h.min + ((1ull << h.width) - 1ull);
+				std::vector<uint8_t>().swap(s.raw);
+				k++;
+			} else {
+				// unpacked slots: the bytes of the image's words are the values
+				s.vec_slots = s.segment_size / s.type_size;
+				s.min_factor = h.min;
+				std::memcpy(s.raw.data(), images[i].first + 9, (size_t)h.count * s.type_size);
+			}
+			s.version++;
+			db.data_size += (int64_t)s.GetDataSize() - (int64_t)before;
+		}
+	}
+	for (size_t i = 0; i + 1 < out.size(); i++) {
+		if (out[i]->type == out[i + 1]->type && out[i + 1]->start == out[i]->start + out[i]->count) {
+			out[i]->SetNext(out[i + 1].get());
+		}
+	}
+	return out;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -848,82 +1306,142 @@ ColumnSegmentCatalog::~ColumnSegmentCatalog() {
 void ColumnSegmentCatalog::AddColumnSegment(ColumnSegment *segment) {
 	if (!segment->is_data_segment) return;
 	std::lock_guard<std::mutex> g(lock);
-	statistics[segment] = AccessStatistics {0};
+	segments.insert(segment);
 }
 
 void ColumnSegmentCatalog::RemoveColumnSegment(ColumnSegment *segment) {
 	std::lock_guard<std::mutex> g(lock);
-	statistics.erase(segment);
+	segments.erase(segment);
 }
 
 void ColumnSegmentCatalog::AddReadAccess(ColumnSegment *segment) {
 	// column_segment_catalog.cpp:37-54
 	if (segment == nullptr || !segment->is_data_segment) return;
-	std::lock_guard<std::mutex> g(lock);
-	auto it = statistics.find(segment);
-	if (it == statistics.end()) {
-		statistics[segment] = AccessStatistics {1};
-	} else {
-		it->second.num_reads++;
-		event_counter++;
-	}
+	segment->num_reads.fetch_add(1, std::memory_order_relaxed);
+	event_counter.fetch_add(1, std::memory_order_relaxed);
 }
 
 idx_t ColumnSegmentCatalog::NumSegments() {
 	std::lock_guard<std::mutex> g(lock);
-	return statistics.size();
+	return segments.size();
+}
+
+std::string ColumnSegmentCatalog::LastBackgroundError() {
+	std::lock_guard<std::mutex> g(lock);
+	return last_background_error;
+}
+
+// Runs f(pool index) for every pool that has work, one host thread per pool when there are several (each pool is
+// its own GPU and stream); the first exception is rethrown after all of them have finished.
+template <typename F>
+static void ForEachPool(const std::vector<char> &has_work, F &&f) {
+	std::vector<size_t> todo;
+	for (size_t p = 0; p < has_work.size(); p++) {
+		if (has_work[p]) todo.push_back(p);
+	}
+	if (todo.size() <= 1) {
+		for (size_t p : todo) f(p);
+		return;
+	}
+	std::vector<std::thread> th;
+	std::vector<std::string> errors(todo.size());
+	for (size_t k = 0; k < todo.size(); k++) {
+		th.emplace_back([&, k]() {
+			try {
+				f(todo[k]);
+			} catch (const std::exception &e) {
+				errors[k] = e.what()[0] ? e.what() : "error";
+			}
+		});
+	}
+	for (auto &t : th) t.join();
+	for (auto &e : errors) {
+		if (!e.empty()) throw InternalException(e);
+	}
 }
 
 void ColumnSegmentCatalog::CompactAllSegments() {
-	std::vector<ColumnSegment *> all;
-	{
-		std::lock_guard<std::mutex> g(lock);
-		for (auto &e : statistics) all.push_back(e.first);
-	}
-	ColumnSegment::CompactMany(db, all);
+	// column_segment_catalog.cpp:56-62.  Pool by pool under the pool's flip lock, so that a segment destroyed
+	// meanwhile (its destructor takes the same lock before it leaves the catalog) is never touched
+	const size_t npools = db.pools.size();
+	ForEachPool(std::vector<char>(npools, 1), [&](size_t p) {
+		SegmentPool &pool = *db.pools[p];
+		std::lock_guard<std::recursive_mutex> flips(pool.flip_lock);
+		std::vector<ColumnSegment *> mine;
+		{
+			std::lock_guard<std::mutex> g(lock);
+			for (auto *s : segments) {
+				if (&s->pool == &pool) mine.push_back(s);
+			}
+		}
+		ColumnSegment::CompactMany(db, mine);
+	});
 }
 
 size_t ColumnSegmentCatalog::GetTotalDataSize() {
 	std::lock_guard<std::mutex> g(lock);
 	size_t data_size = 0;
-	for (auto &e : statistics) data_size += e.first->GetDataSize();
+	for (auto *s : segments) data_size += s->GetDataSize();
 	return data_size;
 }
 
 void ColumnSegmentCatalog::CompressLowestKSegmentsOnce(double compression_rate) {
 	// column_segment_catalog.cpp:79-112.  The reference sorts by num_reads only (ties in unordered_map
-	// order); ties are broken here by the segment's start row, then address, to be deterministic.
-	std::vector<std::pair<ColumnSegment *, AccessStatistics>> v;
+	// order); ties are broken here by the segment's start row, then id, to be deterministic.
+	struct Snap {
+		ColumnSegment *seg;
+		idx_t num_reads, start;
+		uint64_t id;
+		int pool;
+	};
+	std::vector<Snap> v;
 	{
-		std::lock_guard<std::mutex> g(lock);
-		v.assign(statistics.begin(), statistics.end());
+		std::lock_guard<std::mutex> g(lock); // a registered segment is alive: everything needed is copied here
+		v.reserve(segments.size());
+		for (auto *s : segments) {
+			v.push_back(Snap {s, s->num_reads.load(std::memory_order_relaxed), s->start, s->segment_id, s->pool.index});
+		}
 	}
-	std::sort(v.begin(), v.end(), [](const std::pair<ColumnSegment *, AccessStatistics> &l,
-	                                 const std::pair<ColumnSegment *, AccessStatistics> &r) {
-		if (l.second.num_reads != r.second.num_reads) return l.second.num_reads < r.second.num_reads;
-		if (l.first->start != r.first->start) return l.first->start < r.first->start;
-		return l.first < r.first;
+	std::sort(v.begin(), v.end(), [](const Snap &l, const Snap &r) {
+		if (l.num_reads != r.num_reads) return l.num_reads < r.num_reads;
+		if (l.start != r.start) return l.start < r.start;
+		return l.id < r.id;
 	});
-	std::vector<ColumnSegment *> to_compact, to_uncompact;
+	const size_t npools = db.pools.size();
+	std::vector<std::vector<Snap>> to_compact(npools), to_uncompact(npools);
+	std::vector<char> has_work(npools, 0);
 	float cum_sum = 0;
 	idx_t curr_counter = v.size();
 	for (auto &e : v) {
 		cum_sum += 1;
-		if (cum_sum / curr_counter < compression_rate) {
-			to_compact.push_back(e.first);
+		if (cum_sum / curr_counter < compression_rate) { // float / idx_t against a double, as the reference compares
+			to_compact[e.pool].push_back(e);
 		} else {
-			to_uncompact.push_back(e.first);
+			to_uncompact[e.pool].push_back(e);
 		}
+		has_work[e.pool] = 1;
 	}
-	ColumnSegment::CompactMany(db, to_compact);
-	for (auto *s : to_uncompact) s->Uncompact();
-	{
-		std::lock_guard<std::mutex> g(lock);
-		for (auto &e : v) {
-			auto it = statistics.find(e.first);
-			if (it != statistics.end()) it->second.num_reads = 0;
+	ForEachPool(has_work, [&](size_t p) {
+		SegmentPool &pool = *db.pools[p];
+		// a segment's destructor takes this lock before it leaves the catalog: what is still registered once the
+		// lock is held stays alive until it is released.  The id is compared too: the address of a destroyed segment
+		// may already belong to a new one, possibly of another pool, whose destructor this lock would not hold off
+		std::lock_guard<std::recursive_mutex> flips(pool.flip_lock);
+		std::vector<ColumnSegment *> compact, uncompact;
+		{
+			std::lock_guard<std::mutex> g(lock);
+			for (auto &e : to_compact[p]) {
+				if (segments.count(e.seg) && e.seg->segment_id == e.id) compact.push_back(e.seg);
+			}
+			for (auto &e : to_uncompact[p]) {
+				if (segments.count(e.seg) && e.seg->segment_id == e.id) uncompact.push_back(e.seg);
+			}
+			for (auto *s : compact) s->num_reads.store(0, std::memory_order_relaxed);
+			for (auto *s : uncompact) s->num_reads.store(0, std::memory_order_relaxed);
 		}
-	}
+		ColumnSegment::CompactMany(db, compact);
+		for (auto *s : uncompact) s->Uncompact();
+	});
 	event_counter = 0;
 }
 
@@ -937,7 +1455,20 @@ void ColumnSegmentCatalog::EnableBackgroundThreadCompaction(unsigned period_ms) 
 				std::this_thread::sleep_for(std::chrono::milliseconds(5));
 			}
 			if (stop) break;
-			CompressLowestKSegmentsOnce(0.90);
+			// nothing may escape the thread (std::terminate would take the host process down): a failed round —
+			// a HIP error, an allocation failure — is recorded and the next round tries again
+			try {
+				CompressLowestKSegmentsOnce(0.90);
+			} catch (const std::exception &e) {
+				background_errors++;
+				std::lock_guard<std::mutex> g(lock);
+				last_background_error = e.what();
+			} catch (...) {
+				background_errors++;
+				std::lock_guard<std::mutex> g(lock);
+				last_background_error = "unknown exception";
+			}
+			background_rounds++;
 		}
 	});
 }
@@ -980,43 +1511,66 @@ extern "C" const char *adach_last_error(void) {
 	return g_host_error.c_str();
 }
 
-extern "C" adach_db *adach_db_create(int device, int succinct_enabled, int adaptive, int padded, uint64_t arena_bytes) {
+extern "C" adach_db *adach_db_create_pools(const int *devices, int npools, int succinct_enabled, int adaptive, int padded,
+                                           uint64_t arena_bytes, uint64_t decoded_cache_bytes, uint32_t scan_lanes,
+                                           uint32_t prefetch_segments) {
 	adach_db *h = nullptr;
 	Guard([&]() {
-		DBConfig cfg;
-		cfg.succinct_enabled = succinct_enabled != 0;
-		cfg.adaptive_succinct_compression_enabled = adaptive != 0;
-		cfg.succinct_padded_to_next_byte_enabled = padded != 0;
-		auto db = std::unique_ptr<DatabaseInstance>(new DatabaseInstance(device, cfg, arena_bytes));
-		h = new adach_db {std::move(db)};
-	});
-	return h;
-}
-
-extern "C" adach_db *adach_db_create_cached(int device, int succinct_enabled, int adaptive, int padded,
-                                            uint64_t arena_bytes, uint64_t decoded_cache_bytes) {
-	adach_db *h = nullptr;
-	Guard([&]() {
+		if (!devices || npools < 1) throw InternalException("adach_db_create_pools: at least one pool");
 		DBConfig cfg;
 		cfg.succinct_enabled = succinct_enabled != 0;
 		cfg.adaptive_succinct_compression_enabled = adaptive != 0;
 		cfg.succinct_padded_to_next_byte_enabled = padded != 0;
 		cfg.decoded_cache_bytes = decoded_cache_bytes;
-		auto db = std::unique_ptr<DatabaseInstance>(new DatabaseInstance(device, cfg, arena_bytes));
+		if (scan_lanes) cfg.scan_lanes = scan_lanes;
+		if (prefetch_segments) cfg.prefetch_segments = prefetch_segments;
+		std::vector<int> devs(devices, devices + npools);
+		auto db = std::unique_ptr<DatabaseInstance>(new DatabaseInstance(devs, cfg, arena_bytes));
 		h = new adach_db {std::move(db)};
 	});
 	return h;
 }
 
-extern "C" void adach_db_cache_stats(adach_db *h, uint64_t *hits, uint64_t *misses, uint64_t *bytes) {
-	std::lock_guard<std::mutex> g(h->db->pool.lock);
-	if (hits) *hits = h->db->pool.cache_hits;
-	if (misses) *misses = h->db->pool.cache_misses;
-	if (bytes) *bytes = h->db->pool.cache_used;
+extern "C" adach_db *adach_db_create(int device, int succinct_enabled, int adaptive, int padded, uint64_t arena_bytes) {
+	return adach_db_create_pools(&device, 1, succinct_enabled, adaptive, padded, arena_bytes, 0, 0, 0);
 }
 
-// Full scan of a list of segments in the engine's call pattern — ColumnSegment::Scan on vector_size-row vectors
-// (ColumnData::ScanVector, column_data.cpp:92-139) — timed on the host; checksum = wrapping sum of all rows.
+extern "C" adach_db *adach_db_create_cached(int device, int succinct_enabled, int adaptive, int padded,
+                                            uint64_t arena_bytes, uint64_t decoded_cache_bytes) {
+	return adach_db_create_pools(&device, 1, succinct_enabled, adaptive, padded, arena_bytes, decoded_cache_bytes, 0, 0);
+}
+
+extern "C" uint64_t adach_db_num_pools(adach_db *h) {
+	return h->db->pools.size();
+}
+
+extern "C" void adach_db_cache_stats(adach_db *h, uint64_t *hits, uint64_t *misses, uint64_t *bytes) {
+	uint64_t a = 0, b = 0, c = 0;
+	for (auto &p : h->db->pools) {
+		a += p->cache_hits.load();
+		b += p->cache_misses.load();
+		c += p->CacheUsedBytes();
+	}
+	if (hits) *hits = a;
+	if (misses) *misses = b;
+	if (bytes) *bytes = c;
+}
+
+extern "C" void adach_db_prefetch_stats(adach_db *h, uint64_t *batches, uint64_t *prefetched, uint64_t *exhausted) {
+	uint64_t a = 0, b = 0, c = 0;
+	for (auto &p : h->db->pools) {
+		a += p->cache_batches.load();
+		b += p->cache_prefetched.load();
+		c += p->exhausted_events.load();
+	}
+	if (batches) *batches = a;
+	if (prefetched) *prefetched = b;
+	if (exhausted) *exhausted = c;
+}
+
+// Full scan of a chain of segments in the engine's call pattern — ColumnData::ScanVector (column_data.cpp:92-139):
+// InitializeScan on a segment, ColumnSegment::Scan on vector_size-row vectors, on to `next` when a segment is
+// exhausted — timed on the host; checksum = wrapping sum of all rows.
 template <typename T>
 static uint64_t SumTyped(const uint8_t *p, idx_t n) {
 	uint64_t acc = 0;
@@ -1036,30 +1590,69 @@ static uint64_t SumVector(const uint8_t *p, idx_t n, idx_t type_size) {
 	}
 }
 
-extern "C" int adach_full_scan(adach_segment **segs, uint64_t nseg, uint64_t vector_size, uint64_t *checksum,
-                               double *seconds, uint64_t *rows_out) {
+static void ScanRange(adach_segment **segs, uint64_t lo, uint64_t hi, uint64_t vector_size, uint64_t &sum,
+                      uint64_t &rows) {
+	std::vector<uint8_t> vec(vector_size * 8 + 64);
+	ColumnScanState st;
+	for (uint64_t i = lo; i < hi; i++) {
+		ColumnSegment &s = *segs[i]->seg;
+		st.current = &s;
+		s.InitializeScan(st); // state.current->InitializeScan(state) when ScanVector moves to the next segment
+		for (idx_t r = 0; r < s.count; r += vector_size) {
+			idx_t c = std::min<idx_t>(vector_size, s.count - r);
+			st.row_index = s.start + r;
+			Vector v;
+			v.data = vec.data();
+			s.Scan(st, c, v, 0, true);
+			sum += SumVector(vec.data(), c, s.type_size); // the consumer touches every value
+			rows += c;
+		}
+	}
+}
+
+extern "C" int adach_full_scan_mt(adach_segment **segs, uint64_t nseg, uint64_t vector_size, uint32_t threads,
+                                  uint64_t *checksum, double *seconds, uint64_t *rows_out) {
 	return Guard([&]() {
-		std::vector<uint8_t> vec(vector_size * 8 + 64);
-		uint64_t sum = 0, rows = 0;
+		if (threads < 1) threads = 1;
+		if (threads > nseg) threads = (uint32_t)std::max<uint64_t>(1, nseg);
+		std::vector<uint64_t> sums(threads, 0), rows(threads, 0);
+		std::vector<std::string> errors(threads);
 		auto t0 = std::chrono::steady_clock::now();
-		for (uint64_t i = 0; i < nseg; i++) {
-			ColumnSegment &s = *segs[i]->seg;
-			for (idx_t r = 0; r < s.count; r += vector_size) {
-				idx_t c = std::min<idx_t>(vector_size, s.count - r);
-				ColumnScanState st;
-				st.row_index = s.start + r;
-				Vector v;
-				v.data = vec.data();
-				s.Scan(st, c, v, 0, true);
-				sum += SumVector(vec.data(), c, s.type_size); // the consumer touches every value
-				rows += c;
+		if (threads == 1) {
+			ScanRange(segs, 0, nseg, vector_size, sums[0], rows[0]);
+		} else {
+			// one contiguous run of segments per thread: the row-group morsels of a parallel table scan
+			// (src/storage/table/row_group_collection.cpp:119-155)
+			std::vector<std::thread> th;
+			for (uint32_t t = 0; t < threads; t++) {
+				th.emplace_back([&, t]() {
+					try {
+						ScanRange(segs, nseg * t / threads, nseg * (t + 1) / threads, vector_size, sums[t], rows[t]);
+					} catch (const std::exception &e) {
+						errors[t] = e.what()[0] ? e.what() : "error";
+					}
+				});
+			}
+			for (auto &t : th) t.join();
+			for (auto &e : errors) {
+				if (!e.empty()) throw InternalException(e);
 			}
 		}
 		auto t1 = std::chrono::steady_clock::now();
+		uint64_t sum = 0, nrows = 0;
+		for (uint32_t t = 0; t < threads; t++) {
+			sum += sums[t];
+			nrows += rows[t];
+		}
 		if (checksum) *checksum = sum;
 		if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
-		if (rows_out) *rows_out = rows;
+		if (rows_out) *rows_out = nrows;
 	});
+}
+
+extern "C" int adach_full_scan(adach_segment **segs, uint64_t nseg, uint64_t vector_size, uint64_t *checksum,
+                               double *seconds, uint64_t *rows_out) {
+	return adach_full_scan_mt(segs, nseg, vector_size, 1, checksum, seconds, rows_out);
 }
 
 extern "C" void adach_db_destroy(adach_db *h) {
@@ -1076,10 +1669,11 @@ extern "C" adach_segment *adach_segment_create(adach_db *h, int physical_type, u
 	return s;
 }
 
-extern "C" int adach_compress_column(adach_db *h, int compression_type, int physical_type, uint64_t row_group_start,
-                                     const void *values, const uint64_t *validity, uint64_t n,
-                                     adach_segment **out_segments, uint64_t max_segments, uint64_t *out_nseg,
-                                     uint64_t *out_sizes, uint64_t *out_score) {
+extern "C" int adach_checkpoint_column(adach_db *h, int compression_type, int physical_type, uint64_t row_group_start,
+                                       const void *values, const uint64_t *validity, uint64_t n,
+                                       adach_segment **out_segments, uint64_t max_segments, uint64_t *out_nseg,
+                                       uint64_t *out_sizes, uint64_t *out_score, void *out_blocks, uint64_t blocks_cap,
+                                       uint64_t *out_block_offs) {
 	return Guard([&]() {
 		// the checkpoint pipeline of ColumnDataCheckpointer::WriteToDisk (column_data_checkpointer.cpp): analyze
 		// every vector, score, then compress every vector through the winning function's slots
@@ -1096,7 +1690,6 @@ extern "C" int adach_compress_column(adach_db *h, int compression_type, int phys
 		if (out_score) *out_score = fn->final_analyze(*astate);
 		ColumnDataCheckpointer checkpointer(*h->db, type, row_group_start);
 		auto cstate = fn->init_compression(checkpointer, std::move(astate));
-		std::vector<uint64_t> shifted;
 		for (idx_t off = 0; off < n; off += STANDARD_VECTOR_SIZE) {
 			idx_t c = std::min<idx_t>(STANDARD_VECTOR_SIZE, n - off);
 			Vector v;
@@ -1109,6 +1702,20 @@ extern "C" int adach_compress_column(adach_db *h, int compression_type, int phys
 		fn->compress_finalize(*cstate);
 		if (checkpointer.flushed_segments.size() > max_segments) throw InternalException("segment array too small");
 		*out_nseg = checkpointer.flushed_segments.size();
+		if (out_blocks || out_block_offs) {
+			// the block images ConvertToPersistent produced, back to back (8-byte aligned), offsets [nseg + 1]
+			uint64_t off = 0;
+			for (size_t i = 0; i < checkpointer.flushed_blocks.size(); i++) {
+				const auto &b = checkpointer.flushed_blocks[i];
+				if (out_block_offs) out_block_offs[i] = off;
+				if (out_blocks) {
+					if (off + b.size() > blocks_cap) throw InternalException("block buffer too small");
+					std::memcpy(static_cast<uint8_t *>(out_blocks) + off, b.data(), b.size());
+				}
+				off += (b.size() + 7) & ~size_t(7);
+			}
+			if (out_block_offs) out_block_offs[checkpointer.flushed_blocks.size()] = off;
+		}
 		for (size_t i = 0; i < checkpointer.flushed_segments.size(); i++) {
 			out_segments[i] = new adach_segment {std::move(checkpointer.flushed_segments[i])};
 			if (out_sizes) out_sizes[i] = checkpointer.flushed_sizes[i];
@@ -1116,13 +1723,61 @@ extern "C" int adach_compress_column(adach_db *h, int compression_type, int phys
 	});
 }
 
+extern "C" int adach_compress_column(adach_db *h, int compression_type, int physical_type, uint64_t row_group_start,
+                                     const void *values, const uint64_t *validity, uint64_t n,
+                                     adach_segment **out_segments, uint64_t max_segments, uint64_t *out_nseg,
+                                     uint64_t *out_sizes, uint64_t *out_score) {
+	return adach_checkpoint_column(h, compression_type, physical_type, row_group_start, values, validity, n, out_segments,
+	                               max_segments, out_nseg, out_sizes, out_score, nullptr, 0, nullptr);
+}
+
+extern "C" uint64_t adach_segment_block_bytes(adach_segment *s) {
+	ColumnSegment &seg = *s->seg;
+	const uint8_t w = seg.IsBitCompressed() ? seg.Width() : (uint8_t)(8 * seg.type_size);
+	return adac_block_bytes(seg.count, w); // an upper bound before the segment has been compacted
+}
+
+extern "C" int adach_segments_persist(adach_db *h, adach_segment **segs, uint64_t nseg, void *out, uint64_t cap,
+                                      uint64_t *out_offs) {
+	return Guard([&]() {
+		std::vector<ColumnSegment *> v;
+		for (uint64_t i = 0; i < nseg; i++) v.push_back(segs[i]->seg.get());
+		std::vector<std::vector<uint8_t>> images;
+		ColumnSegment::ConvertManyToPersistent(*h->db, v, images);
+		uint64_t off = 0;
+		for (uint64_t i = 0; i < nseg; i++) {
+			out_offs[i] = off;
+			if (off + images[i].size() > cap) throw InternalException("block buffer too small");
+			std::memcpy(static_cast<uint8_t *>(out) + off, images[i].data(), images[i].size());
+			off += (images[i].size() + 7) & ~size_t(7);
+		}
+		out_offs[nseg] = off;
+	});
+}
+
+extern "C" int adach_segments_load(adach_db *h, const void *blocks, const uint64_t *offs, const uint64_t *lens,
+                                   const uint64_t *starts, uint64_t nseg, adach_segment **out_segments) {
+	return Guard([&]() {
+		std::vector<std::pair<const uint8_t *, size_t>> images;
+		std::vector<idx_t> st;
+		for (uint64_t i = 0; i < nseg; i++) {
+			images.emplace_back(static_cast<const uint8_t *>(blocks) + offs[i], (size_t)lens[i]);
+			st.push_back(starts[i]);
+		}
+		auto segs = ColumnSegment::CreatePersistentSegments(*h->db, images, st);
+		for (uint64_t i = 0; i < nseg; i++) out_segments[i] = new adach_segment {std::move(segs[i])};
+	});
+}
+
 extern "C" int adach_db_reserve_staging(adach_db *h, uint64_t bytes) {
 	return Guard([&]() {
 		// page-locking the upload buffer is the one slow step of a first compaction round (hipHostMalloc: ~20 ms
 		// per 100 MB): an engine sizes it once, here, instead of inside the first policy step
-		std::lock_guard<std::mutex> pg(h->db->pool.lock);
-		h->db->pool.PinnedStaging(bytes);
-		h->db->pool.Staging(bytes);
+		for (auto &p : h->db->pools) {
+			std::lock_guard<std::mutex> pg(p->lock);
+			p->PinnedStaging(bytes);
+			p->Staging(bytes);
+		}
 	});
 }
 
@@ -1168,6 +1823,8 @@ extern "C" int adach_segment_scan(adach_segment *s, uint64_t row_index, uint64_t
 	return Guard([&]() {
 		ColumnScanState st;
 		st.row_index = row_index;
+		st.current = s->seg.get();
+		s->seg->InitializeScan(st);
 		Vector v;
 		v.data = static_cast<data_ptr_t>(result);
 		s->seg->Scan(st, count, v, result_offset, entire_vector != 0);
@@ -1210,6 +1867,12 @@ extern "C" int adach_segment_function(adach_segment *s) {
 extern "C" uint64_t adach_segment_data_size(adach_segment *s) {
 	return s->seg->GetDataSize();
 }
+extern "C" int adach_segment_pool(adach_segment *s) {
+	return s->seg->pool.index;
+}
+extern "C" int adach_segment_persistent(adach_segment *s) {
+	return s->seg->segment_type == ColumnSegmentType::PERSISTENT;
+}
 
 extern "C" int adach_catalog_compact_all(adach_db *h) {
 	return Guard([&]() { h->db->catalog.CompactAllSegments(); });
@@ -1229,11 +1892,25 @@ extern "C" int adach_catalog_enable_background(adach_db *h, unsigned period_ms) 
 extern "C" int adach_catalog_disable_background(adach_db *h) {
 	return Guard([&]() { h->db->catalog.DisableBackgroundThreadCompaction(); });
 }
+extern "C" void adach_catalog_background_stats(adach_db *h, uint64_t *rounds, uint64_t *errors, char *last_error,
+                                               uint64_t cap) {
+	if (rounds) *rounds = h->db->catalog.BackgroundRounds();
+	if (errors) *errors = h->db->catalog.BackgroundErrors();
+	if (last_error && cap) {
+		const std::string e = h->db->catalog.LastBackgroundError();
+		std::snprintf(last_error, cap, "%s", e.c_str());
+	}
+}
 extern "C" int64_t adach_db_data_size(adach_db *h) {
 	return h->db->data_size.load();
 }
 extern "C" uint64_t adach_db_arena_used_bytes(adach_db *h) {
-	return h->db->pool.UsedWords() * 8;
+	uint64_t w = 0;
+	for (auto &p : h->db->pools) w += p->UsedWords();
+	return w * 8;
+}
+extern "C" uint64_t adach_db_pool_arena_used_bytes(adach_db *h, uint32_t pool) {
+	return pool < h->db->pools.size() ? h->db->pools[pool]->UsedWords() * 8 : 0;
 }
 extern "C" int adach_type_is_supported(int physical_type) {
 	return SuccinctFun::TypeIsSupported((PhysicalType)physical_type) ? 1 : 0;

@@ -15,7 +15,21 @@ HOST_SIGNATURES = {
     "adach_db_create": (_vp, [_int, _int, _int, _int, _u64]),
     "adach_db_destroy": (None, [_vp]),
     "adach_db_create_cached": (_vp, [_int, _int, _int, _int, _u64, _u64]),
+    "adach_db_create_pools": (_vp, [C.POINTER(_int), _int, _int, _int, _int, _u64, _u64, _u32, _u32]),
+    "adach_db_num_pools": (_u64, [_vp]),
     "adach_db_cache_stats": (None, [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
+    "adach_db_prefetch_stats": (None, [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
+    "adach_full_scan_mt": (_int, [C.POINTER(_vp), _u64, _u64, _u32, C.POINTER(_u64), C.POINTER(C.c_double),
+                                  C.POINTER(_u64)]),
+    "adach_checkpoint_column": (_int, [_vp, _int, _int, _u64, _vp, _vp, _u64, C.POINTER(_vp), _u64, C.POINTER(_u64),
+                                       C.POINTER(_u64), C.POINTER(_u64), _vp, _u64, C.POINTER(_u64)]),
+    "adach_segment_block_bytes": (_u64, [_vp]),
+    "adach_segments_persist": (_int, [_vp, C.POINTER(_vp), _u64, _vp, _u64, C.POINTER(_u64)]),
+    "adach_segments_load": (_int, [_vp, _vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64), _u64, C.POINTER(_vp)]),
+    "adach_segment_pool": (_int, [_vp]),
+    "adach_segment_persistent": (_int, [_vp]),
+    "adach_catalog_background_stats": (None, [_vp, C.POINTER(_u64), C.POINTER(_u64), C.c_char_p, _u64]),
+    "adach_db_pool_arena_used_bytes": (_u64, [_vp, _u32]),
     "adach_full_scan": (_int, [C.POINTER(_vp), _u64, _u64, C.POINTER(_u64), C.POINTER(C.c_double), C.POINTER(_u64)]),
     "adach_db_reserve_staging": (_int, [_vp, _u64]),
     "adach_db_data_size": (_i64, [_vp]),
@@ -75,12 +89,15 @@ def _p(a):
 
 
 class Database:
-    """DBConfig flags + one GPU segment pool + the ColumnSegmentCatalog."""
+    """DBConfig flags + one segment pool per GPU + the ColumnSegmentCatalog.  device: one HIP device, or a list of
+    them = one pool each (the same device may be listed several times); arena_bytes / decoded_cache_bytes per pool."""
 
     def __init__(self, device=0, succinct_enabled=True, adaptive=False, padded=False, arena_bytes=1 << 30,
-                 decoded_cache_bytes=0):
-        self._h = hlib().adach_db_create_cached(device, int(succinct_enabled), int(adaptive), int(padded), arena_bytes,
-                                                decoded_cache_bytes)
+                 decoded_cache_bytes=0, scan_lanes=0, prefetch_segments=0):
+        devices = [device] if isinstance(device, int) else list(device)
+        arr = (_int * len(devices))(*devices)
+        self._h = hlib().adach_db_create_pools(arr, len(devices), int(succinct_enabled), int(adaptive), int(padded),
+                                               arena_bytes, decoded_cache_bytes, scan_lanes, prefetch_segments)
         if not self._h:
             raise HostError("adach_db_create: %s" % hlib().adach_last_error().decode())
         self.segments = []
@@ -143,6 +160,64 @@ class Database:
             self.segments.append(s)
         return segs, [sizes[i] for i in range(nseg.value)], score.value
 
+    def checkpoint_column(self, values, validity=None, row_group_start=0, compression_type=10):
+        """compress_column + the block images ConvertToPersistent yields for the flushed segments.
+        Returns (segments, sizes, score, [image bytes per segment])."""
+        values = np.ascontiguousarray(values)
+        if validity is not None:
+            validity = np.ascontiguousarray(validity, dtype=np.uint64)
+        cap = len(values) // 2048 + 8
+        arr = (_vp * cap)()
+        sizes = (_u64 * cap)()
+        offs = (_u64 * (cap + 1))()
+        nseg, score = _u64(), _u64()
+        blob = np.zeros(values.nbytes + cap * 64 + 4096, dtype=np.uint8)
+        _ok(hlib().adach_checkpoint_column(self._h, compression_type, physical_type(values.dtype), row_group_start,
+                                           _p(values), _p(validity), len(values), arr, cap, C.byref(nseg), sizes,
+                                           C.byref(score), _p(blob), blob.nbytes, offs), "checkpoint_column")
+        segs, row, images = [], row_group_start, []
+        for i in range(nseg.value):
+            s = Segment.__new__(Segment)
+            s.db, s.dtype, s.start, s._h = self, values.dtype, row, arr[i]
+            row += s.count
+            segs.append(s)
+            self.segments.append(s)
+            if compression_type == 10:
+                n = hlib().adach_segment_block_bytes(s._h)
+                images.append(blob[offs[i]:offs[i] + n].tobytes())
+        return segs, [sizes[i] for i in range(nseg.value)], score.value, images
+
+    def persist(self, segments):
+        """ConvertToPersistent for a list of segments -> [image bytes]."""
+        arr = (_vp * len(segments))(*[s._h for s in segments])
+        cap = sum(hlib().adach_segment_block_bytes(s._h) + 8 for s in segments) + 64
+        blob = np.zeros(cap, dtype=np.uint8)
+        offs = (_u64 * (len(segments) + 1))()
+        _ok(hlib().adach_segments_persist(self._h, arr, len(segments), _p(blob), cap, offs), "persist")
+        return [blob[offs[i]:offs[i] + hlib().adach_segment_block_bytes(s._h)].tobytes()
+                for i, s in enumerate(segments)]
+
+    def load(self, images, dtype, starts):
+        """Segments from block images (CreatePersistentSegments)."""
+        lens = np.array([len(b) for b in images], dtype=np.uint64)
+        padded = [(int(n) + 7) & ~7 for n in lens]
+        offs = np.concatenate([[0], np.cumsum(padded)[:-1]]).astype(np.uint64) if len(images) else np.zeros(0, np.uint64)
+        blob = np.zeros(int(sum(padded)) + 8, dtype=np.uint8)
+        for o, b in zip(offs, images):
+            blob[int(o):int(o) + len(b)] = np.frombuffer(b, dtype=np.uint8)
+        st = np.ascontiguousarray(starts, dtype=np.uint64)
+        arr = (_vp * len(images))()
+        _ok(hlib().adach_segments_load(self._h, _p(blob), offs.ctypes.data_as(C.POINTER(_u64)),
+                                       lens.ctypes.data_as(C.POINTER(_u64)), st.ctypes.data_as(C.POINTER(_u64)),
+                                       len(images), arr), "load")
+        segs = []
+        for i in range(len(images)):
+            s = Segment.__new__(Segment)
+            s.db, s.dtype, s.start, s._h = self, np.dtype(dtype), int(st[i]), arr[i]
+            segs.append(s)
+            self.segments.append(s)
+        return segs
+
     def reserve_staging(self, nbytes):
         _ok(hlib().adach_db_reserve_staging(self._h, nbytes), "reserve_staging")
 
@@ -151,14 +226,26 @@ class Database:
         hlib().adach_db_cache_stats(self._h, C.byref(h), C.byref(m), C.byref(b))
         return {"hits": h.value, "misses": m.value, "bytes": b.value}
 
-    def full_scan(self, segments=None, vector_size=2048):
-        """Scan every row of `segments` in vector_size-row ColumnSegment::Scan calls (C++ loop, timed on the
-        host).  Returns (checksum, seconds, rows)."""
+    def prefetch_stats(self):
+        a, b, c = _u64(), _u64(), _u64()
+        hlib().adach_db_prefetch_stats(self._h, C.byref(a), C.byref(b), C.byref(c))
+        return {"batches": a.value, "prefetched": b.value, "arena_exhausted": c.value}
+
+    def background_stats(self):
+        r, e = _u64(), _u64()
+        buf = C.create_string_buffer(512)
+        hlib().adach_catalog_background_stats(self._h, C.byref(r), C.byref(e), buf, 512)
+        return {"rounds": r.value, "errors": e.value, "last_error": buf.value.decode()}
+
+    def full_scan(self, segments=None, vector_size=2048, threads=1):
+        """Scan every row of `segments` the way ColumnData::ScanVector does (InitializeScan per segment,
+        vector_size-row ColumnSegment::Scan calls; C++ loop, timed on the host), with `threads` consumers each taking
+        a contiguous run of the segments.  Returns (checksum, seconds, rows)."""
         segments = self.segments if segments is None else segments
         arr = (_vp * len(segments))(*[s._h for s in segments])
         cs, sec, rows = _u64(), C.c_double(), _u64()
-        _ok(hlib().adach_full_scan(arr, len(segments), vector_size, C.byref(cs), C.byref(sec), C.byref(rows)),
-            "full_scan")
+        _ok(hlib().adach_full_scan_mt(arr, len(segments), vector_size, threads, C.byref(cs), C.byref(sec),
+                                      C.byref(rows)), "full_scan")
         return cs.value, sec.value, rows.value
 
     def compact_all(self):
@@ -177,6 +264,10 @@ class Database:
     num_segments = property(lambda s: hlib().adach_catalog_num_segments(s._h))
     data_size = property(lambda s: hlib().adach_db_data_size(s._h))
     arena_used_bytes = property(lambda s: hlib().adach_db_arena_used_bytes(s._h))
+    num_pools = property(lambda s: hlib().adach_db_num_pools(s._h))
+
+    def pool_arena_used_bytes(self, pool):
+        return hlib().adach_db_pool_arena_used_bytes(self._h, pool)
 
 
 class Segment:
@@ -234,3 +325,5 @@ class Segment:
     compacted = property(lambda s: bool(hlib().adach_segment_compacted(s._h)))
     function = property(lambda s: hlib().adach_segment_function(s._h))
     data_size = property(lambda s: hlib().adach_segment_data_size(s._h))
+    pool = property(lambda s: hlib().adach_segment_pool(s._h))
+    persistent = property(lambda s: bool(hlib().adach_segment_persistent(s._h)))

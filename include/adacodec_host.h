@@ -7,6 +7,9 @@
  *
  * Reference interfaces mirrored (paths relative to the reference checkout):
  *   adach_db_create               DBConfig flags (src/include/duckdb/main/config.hpp:189-197) + one GPU segment pool
+ *   adach_db_create_pools         the same with one segment pool per listed device (per-GPU segment pools; a segment
+ *                                 lives in pool id mod pools — the unit of independence is the segment,
+ *                                 src/storage/table/row_group_collection.cpp:119-155)
  *   adach_segment_create          ColumnSegment::CreateTransientSegment (src/storage/table/column_segment.cpp:45-82)
  *   adach_segment_append          ColumnSegment::Append (column_segment.cpp:247-271) -> append slot (succinct.cpp:308-322)
  *   adach_segment_scan            ColumnSegment::Scan / ScanPartial (column_segment.cpp:137-188) -> scan_vector / scan_partial
@@ -36,7 +39,21 @@ adach_db *adach_db_create(int device, int succinct_enabled, int adaptive, int pa
  * engine's 2048-row scan_vector calls cost one device decode + one PCIe copy per segment (0 = off) */
 adach_db *adach_db_create_cached(int device, int succinct_enabled, int adaptive, int padded, uint64_t arena_bytes,
                                  uint64_t decoded_cache_bytes);
+/* One segment pool per entry of devices[] (the same device may be listed more than once).  arena_bytes and
+ * decoded_cache_bytes are PER POOL.  scan_lanes: decode + copy-down streams per pool (0 = 4); prefetch_segments:
+ * segments per decode batch, i.e. how far a sequential scan decodes ahead of its consumer (0 = 8, at most 48). */
+adach_db *adach_db_create_pools(const int *devices, int npools, int succinct_enabled, int adaptive, int padded,
+                                uint64_t arena_bytes, uint64_t decoded_cache_bytes, uint32_t scan_lanes,
+                                uint32_t prefetch_segments);
+uint64_t adach_db_num_pools(adach_db *db);
 void adach_db_cache_stats(adach_db *db, uint64_t *hits, uint64_t *misses, uint64_t *bytes);
+/* decode batches enqueued, segments decoded ahead of their first touch, segments a compaction left unpacked because
+ * the arena was full (summed over the pools) */
+void adach_db_prefetch_stats(adach_db *db, uint64_t *batches, uint64_t *prefetched, uint64_t *exhausted);
+/* adach_full_scan with `threads` consumers, each scanning one contiguous run of the segments (the row-group morsels
+ * of a parallel table scan, src/storage/table/row_group_collection.cpp:119-155) */
+int adach_full_scan_mt(adach_segment **segs, uint64_t nseg, uint64_t vector_size, uint32_t threads, uint64_t *checksum,
+                       double *seconds, uint64_t *rows);
 /* Full scan of segs[0..nseg) the way ColumnData::ScanVector drives the codec (vector_size rows per
  * ColumnSegment::Scan call), timed on the host; checksum = wrapping sum of every scanned row. */
 int adach_full_scan(adach_segment **segs, uint64_t nseg, uint64_t vector_size, uint64_t *checksum, double *seconds,
@@ -56,6 +73,25 @@ uint64_t adach_db_arena_used_bytes(adach_db *db);  /* HBM actually held by packe
 int adach_compress_column(adach_db *db, int compression_type, int physical_type, uint64_t row_group_start,
                           const void *values, const uint64_t *validity, uint64_t n, adach_segment **out_segments,
                           uint64_t max_segments, uint64_t *out_nseg, uint64_t *out_sizes, uint64_t *out_score);
+/* The same, also returning what ColumnCheckpointState::FlushSegment -> ColumnSegment::ConvertToPersistent yields for
+ * every flushed segment — the conversion the reference leaves empty for SUCCINCT (src/storage/table/
+ * column_segment.cpp:529-533): block images (include/adacodec.h) back to back at 8-byte aligned offsets,
+ * out_block_offs[0 .. nseg] (image i = [offs[i], offs[i] + adac_block_bytes)).  All images of the column are built
+ * in ONE device pass per pool.  out_blocks / out_block_offs may be NULL. */
+int adach_checkpoint_column(adach_db *db, int compression_type, int physical_type, uint64_t row_group_start,
+                            const void *values, const uint64_t *validity, uint64_t n, adach_segment **out_segments,
+                            uint64_t max_segments, uint64_t *out_nseg, uint64_t *out_sizes, uint64_t *out_score,
+                            void *out_blocks, uint64_t blocks_cap, uint64_t *out_block_offs);
+/* ConvertToPersistent for any list of segments (compacting those that still need it): images as above. */
+uint64_t adach_segment_block_bytes(adach_segment *seg); /* upper bound of the segment's image size */
+int adach_segments_persist(adach_db *db, adach_segment **segs, uint64_t nseg, void *out, uint64_t cap,
+                           uint64_t *out_offs /* nseg + 1 */);
+/* ColumnSegment::CreatePersistentSegment for a batch (src/storage/table/column_segment.cpp:25-43): segments whose
+ * packed words are moved into the pools' arenas with one upload and one device pass per pool.  lens[i]:
+ * adac_block_bytes of image i; starts[i]: its first row. */
+int adach_segments_load(adach_db *db, const void *blocks, const uint64_t *offs, const uint64_t *lens,
+                        const uint64_t *starts, uint64_t nseg, adach_segment **out_segments);
+
 /* present[0..15] = which of the sixteen slots the function table fills, in the reference's order (init_analyze,
  * analyze, final_analyze, init_compression, compress, compress_finalize, init_scan, scan_vector, scan_partial,
  * fetch_row, skip, init_segment, init_append, append, finalize_append, revert_append): succinct.cpp:335-343 leaves
@@ -82,6 +118,8 @@ uint32_t adach_segment_width(adach_segment *seg);
 int adach_segment_compacted(adach_segment *seg);
 int adach_segment_function(adach_segment *seg); /* CompressionType: 1 uncompressed, 10 succinct */
 uint64_t adach_segment_data_size(adach_segment *seg);
+int adach_segment_pool(adach_segment *seg);       /* index of the pool (GPU) the segment lives in */
+int adach_segment_persistent(adach_segment *seg); /* ColumnSegmentType::PERSISTENT */
 
 int adach_catalog_compact_all(adach_db *db);
 uint64_t adach_catalog_total_data_size(adach_db *db);
@@ -90,6 +128,10 @@ uint64_t adach_catalog_num_segments(adach_db *db);
 int adach_catalog_policy_step(adach_db *db, double compression_rate);
 int adach_catalog_enable_background(adach_db *db, unsigned period_ms);
 int adach_catalog_disable_background(adach_db *db);
+/* rounds the background thread has run, rounds that failed (the thread records the error and carries on), and the
+ * last error text */
+void adach_catalog_background_stats(adach_db *db, uint64_t *rounds, uint64_t *errors, char *last_error, uint64_t cap);
+uint64_t adach_db_pool_arena_used_bytes(adach_db *db, uint32_t pool);
 
 #ifdef __cplusplus
 }

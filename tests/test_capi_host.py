@@ -154,7 +154,9 @@ def test_null_arguments_are_refused_not_dereferenced(adac):
     host_only = {"adac_status_string", "adac_last_error", "adac_abi_version", "adac_type_is_supported", "adac_type_size",
                  "adac_hi", "adac_width", "adac_packed_words", "adac_size_in_bytes", "adac_arena_words",
                  "adac_tile_values", "adac_set_tuning", "adac_block_bytes", "adac_stored_min", "adac_block_write",
-                 "adac_bp_plan_encodable"}
+                 "adac_bp_plan_encodable", "adac_block_stride"}
+    assert L.adac_event_done(None) == 0               # a query, not a status: "not finished" for a NULL event
+    host_only.add("adac_event_done")
     for name, (res, args) in adac.SIGNATURES.items():
         if name in host_only:
             continue
