@@ -32,23 +32,48 @@ def load(db, lay, dtype, values):
         row += count
 
 
-def plugin_scan(host, lay, n=10_000_000):
+PCIE_GBS = 63.0  # PCIe Gen5 x16, one direction (spec)
+
+
+def plugin_scan(host, lay, n=int(os.environ.get("PLUGIN_SCAN_ROWS", 200_000_000))):
     values = np.arange(n, dtype=np.uint32)  # SuccinctSequentialInsert / C1 column
-    out = {"rows": n, "dtype": "u32", "vector_size": 2048, "variants": {}}
-    for name, cache in (("per_vector_device_decode", 0), ("decoded_segment_cache", 256 << 20)):
-        db = host.Database(0, arena_bytes=256 << 20, decoded_cache_bytes=cache)
+    out = {"rows": n, "dtype": "u32", "vector_size": 2048, "pcie_spec_GBps": PCIE_GBS, "variants": {}}
+    ncpu = len(os.sched_getaffinity(0))
+    variants = [("per_vector_device_decode", dict(decoded_cache_bytes=0), (1,), min(n, 4_000_000)),
+                ("decoded_segment_cache", dict(decoded_cache_bytes=192 << 20, scan_lanes=8, prefetch_segments=8),
+                 (1, 2, 4, 8, 16), n),
+                ("decoded_segment_cache_2_pools_on_one_gpu",
+                 dict(device=[0, 0], decoded_cache_bytes=96 << 20, scan_lanes=4, prefetch_segments=8), (1, 8), n)]
+    for name, kw, thread_counts, rows_here in variants:
+        kw = dict(kw)
+        device = kw.pop("device", 0)
+        db = host.Database(device, arena_bytes=1 << 30, **kw)
         t0 = time.perf_counter()
-        load(db, lay, np.uint32, values)
+        load(db, lay, np.uint32, values[:rows_here])
         db.compact_all()
         t_load = time.perf_counter() - t0
-        cs, sec_cold, rows = db.full_scan()
-        assert cs == n * (n - 1) // 2
-        cs, sec_warm, rows = db.full_scan()
-        out["variants"][name] = {
-            "load_and_compact_s": t_load, "total_data_size": db.total_data_size,
-            "cold_scan_rows_per_s": rows / sec_cold, "warm_scan_rows_per_s": rows / sec_warm,
-            "cache": db.cache_stats(),
-        }
+        rec = {"rows": rows_here, "load_and_compact_s": t_load, "total_data_size": db.total_data_size, "scans": {}}
+        for th in thread_counts:
+            if th > ncpu:
+                continue
+            # cold: the cache (192 MiB) is smaller than the column (800 MB) and LRU, so every pass decodes and copies
+            # every segment again; warm is measured on a prefix that fits
+            cs, sec_cold, rows = db.full_scan(threads=th)
+            assert cs == rows_here * (rows_here - 1) // 2
+            cs, sec_cold2, rows = db.full_scan(threads=th)
+            sec = min(sec_cold, sec_cold2)
+            rec["scans"]["threads_%d" % th] = {
+                "cold_scan_rows_per_s": rows / sec, "d2h_GBps": rows * 4 / sec / 1e9,
+                "fraction_of_pcie_spec": rows * 4 / sec / 1e9 / PCIE_GBS}
+        if kw.get("decoded_cache_bytes"):
+            fit = [s for s in db.segments][:400]   # ~100 MB: stays resident
+            db.full_scan(fit)
+            for th in (1, 8):
+                cs, sec_warm, rows = db.full_scan(fit, threads=th)
+                rec["scans"]["warm_threads_%d" % th] = {"rows_per_s": rows / sec_warm}
+        rec["cache"] = db.cache_stats()
+        rec["prefetch"] = db.prefetch_stats()
+        out["variants"][name] = rec
         db.close()
     return out
 

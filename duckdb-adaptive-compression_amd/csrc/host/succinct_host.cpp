@@ -178,6 +178,7 @@ void SegmentPool::Free(uint64_t off, uint64_t words) {
 		free_list.erase(next);
 	}
 	free_list[off] = words;
+	free_generation++;
 }
 
 uint64_t SegmentPool::UsedWords() {
@@ -754,15 +755,23 @@ CacheEntry *ColumnSegment::PinDecoded(bool may_schedule) {
 		}
 		std::unique_lock<std::mutex> held;
 		ScanLane &lane = p.AcquireLane(held);
-		adac_status st = adac_unpack_jobs(lane.ctx, (int)type, jobs.data(), jobs.size(), p.d_arena, lane.d_stage);
-		for (size_t i = 0; st == ADAC_OK && i < items.size();) {
-			size_t j = i + 1;
-			while (j < items.size() && items[j].e->slot == items[j - 1].e->slot + 1) j++;
-			// whole slots of the run but the last, whose tail past its rows is not needed
-			const size_t bytes = (j - 1 - i) * SegmentPool::kCacheSlotBytes + items[j - 1].e->bytes;
-			st = adac_memcpy_d2h_async(lane.ctx, items[i].e->data,
-			                           static_cast<uint8_t *>(lane.d_stage) + i * SegmentPool::kCacheSlotBytes, bytes);
-			i = j;
+		adac_status st;
+		if (db.config.zero_copy_decode) {
+			// the decode kernel stores straight into the page-locked blocks (they are mapped into the GPU's address
+			// space): the rows cross PCIe as the kernel's own 16-byte stores — no device staging, no copy engine
+			for (size_t i = 0; i < items.size(); i++) jobs[i].out_off = (uint64_t)items[i].e->slot * slot_elems;
+			st = adac_unpack_jobs(lane.ctx, (int)type, jobs.data(), jobs.size(), p.d_arena, p.cache_slab);
+		} else {
+			st = adac_unpack_jobs(lane.ctx, (int)type, jobs.data(), jobs.size(), p.d_arena, lane.d_stage);
+			for (size_t i = 0; st == ADAC_OK && i < items.size();) {
+				size_t j = i + 1;
+				while (j < items.size() && items[j].e->slot == items[j - 1].e->slot + 1) j++;
+				// whole slots of the run but the last, whose tail past its rows is not needed
+				const size_t bytes = (j - 1 - i) * SegmentPool::kCacheSlotBytes + items[j - 1].e->bytes;
+				st = adac_memcpy_d2h_async(lane.ctx, items[i].e->data,
+				                           static_cast<uint8_t *>(lane.d_stage) + i * SegmentPool::kCacheSlotBytes, bytes);
+				i = j;
+			}
 		}
 		adac_event *ev = nullptr;
 		if (st == ADAC_OK) st = adac_event_record(lane.ctx, &ev);
@@ -872,7 +881,10 @@ idx_t ColumnSegment::FinalizeAppend() {
 
 bool ColumnSegment::NeedsCompaction() const {
 	// column_segment.cpp:278-280
-	return !(compacted || !function || num_elements == 0 || !succinct_possible);
+	if (compacted || !function || num_elements == 0 || !succinct_possible) return false;
+	// a segment the arena had no room for is not tried again (by every scan call, in the non-adaptive mode) until
+	// some block of its pool has been freed
+	return !(arena_refused && refused_generation == pool.free_generation.load());
 }
 
 void ColumnSegment::Compact() {
@@ -1008,9 +1020,11 @@ void ColumnSegment::CompactGroup(DatabaseInstance &db, SegmentPool &pool, int pt
 				adac_segment_desc d;
 				const uint64_t need = adac_arena_words(counts[i], w);
 				if (!pool.TryAllocate(need, d.word_off)) {
-					// the arena is full: the segment keeps its unpacked form and is tried again by the next round
+					// the arena is full: the segment keeps its unpacked form; it is tried again once space was freed
 					skipped[i] = 1;
 					pool.exhausted_events++;
+					segs[i]->arena_refused = true;
+					segs[i]->refused_generation = pool.free_generation.load();
 					continue;
 				}
 				rollback.blocks.emplace_back(d.word_off, need);
@@ -1078,6 +1092,7 @@ void ColumnSegment::FinishCompaction(bool packed, uint8_t width, uint64_t mn, ui
 		word_off = off;
 		arena_words = adac_arena_words(count, width);
 		device_min = stored_min;
+		arena_refused = false;
 		// the unpacked image is gone, as after SDSL's realloc shrink
 		if (graveyard) {
 			graveyard->emplace_back(std::move(raw));
@@ -1524,6 +1539,7 @@ extern "C" adach_db *adach_db_create_pools(const int *devices, int npools, int s
 		cfg.decoded_cache_bytes = decoded_cache_bytes;
 		if (scan_lanes) cfg.scan_lanes = scan_lanes;
 		if (prefetch_segments) cfg.prefetch_segments = prefetch_segments;
+		if (const char *z = std::getenv("ADACH_ZERO_COPY")) cfg.zero_copy_decode = z[0] != '0'; // A/B knob
 		std::vector<int> devs(devices, devices + npools);
 		auto db = std::unique_ptr<DatabaseInstance>(new DatabaseInstance(devs, cfg, arena_bytes));
 		h = new adach_db {std::move(db)};

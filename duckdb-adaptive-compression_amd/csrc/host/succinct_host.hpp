@@ -41,6 +41,10 @@
 
 #include "adacodec.h"
 
+#ifndef ADACH_ZERO_COPY_DEFAULT
+#define ADACH_ZERO_COPY_DEFAULT true
+#endif
+
 namespace adacodec {
 
 using idx_t = uint64_t;
@@ -77,6 +81,9 @@ struct DBConfig {
 	uint64_t decoded_cache_bytes = 0;
 	uint32_t scan_lanes = 4;        // decode + copy-down streams per pool
 	uint32_t prefetch_segments = 8; // segments per decode batch = how far a scan decodes ahead of its consumer
+	// true: the decode kernels of the scan lanes store straight into the page-locked cache blocks (zero copy);
+	// false: they decode into device staging and a copy engine brings the blocks down
+	bool zero_copy_decode = ADACH_ZERO_COPY_DEFAULT;
 };
 
 // The slice of duckdb::UnifiedVectorFormat the append slot reads (data, selection vector, validity mask).
@@ -237,6 +244,7 @@ public:
 	void Free(uint64_t word_off, uint64_t words);
 	uint64_t UsedWords();
 	std::atomic<uint64_t> exhausted_events {0}; // segments a compaction left unpacked for lack of arena space
+	std::atomic<uint64_t> free_generation {0};  // bumped by every Free: "has space come back since I was refused?"
 
 	// ---- decoded-segment cache: one page-locked slab cut into block-sized slots, LRU, entries pinned by scan states
 	static constexpr size_t kCacheSlotBytes = 262144;
@@ -452,6 +460,8 @@ private:
 	std::vector<uint64_t> validity;    // NULL rows of the append phase (consumed by the first compaction)
 	bool any_null = false;
 	bool appended_via_succinct = false; // true: min/max follow the append rule; false: the recompaction rule
+	bool arena_refused = false;         // the last compaction found no room in the arena ...
+	uint64_t refused_generation = 0;    // ... at this free_generation of the pool
 };
 
 } // namespace adacodec
