@@ -328,6 +328,12 @@ extern "C" int adac_set_tuning(const char *name, int value) {
 // context
 // ------------------------------------------------------------------------------------------------
 
+extern "C" int adac_device_count(void) {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
 extern "C" adac_status adac_ctx_create(int device, void *external_stream, adac_ctx **out) {
 	if (!out) return ADAC_ERR_INVALID_ARGUMENT;
 	*out = nullptr;

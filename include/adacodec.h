@@ -152,6 +152,10 @@ int adac_set_tuning(const char *name, int value);
  * contexts (one per engine worker, or one per GPU) are independent; the host-only helpers are re-entrant.
  * ------------------------------------------------------------------------------------------- */
 
+/* gfx950 devices visible to this process (hipGetDeviceCount); 0 when there is none or the runtime is unusable.
+ * A host builds one segment pool per device from it. */
+int adac_device_count(void);
+
 /* Binds to HIP device `device`.  external_stream: a hipStream_t owned by the caller (e.g. the engine's or
  * torch's current stream) or NULL to create a private non-blocking stream. */
 adac_status adac_ctx_create(int device, void *external_stream, adac_ctx **out);
