@@ -58,6 +58,8 @@ struct adac_layout {
 	bool is_signed = false;
 	uint64_t null_bits = 0; // NullValue<T>() as the bit pattern of T, zero-extended (null_value.hpp:26-28)
 	uint64_t nseg = 0, ntiles = 0, total_values = 0, value_span = 0, max_arena_words = 0;
+	bool single_pass_ok = true; // every segment fits the single-pass encode kernel's registers
+	void *d_scan_state = nullptr; // its look-back words + ticket (allocated on first use)
 	bool dense_values = true; // segments back to back from element 0: no element index between them is unowned
 	std::vector<uint32_t> counts;
 	std::vector<uint64_t> val_offs;
@@ -316,6 +318,7 @@ extern "C" int adac_set_tuning(const char *name, int value) {
 	else if (n == "scan_probe") adac::g_tuning.scan_probe = value;
 	else if (n == "sel_debug") adac::g_tuning.sel_debug = value;
 	else if (n == "grouped_repack") adac::g_tuning.grouped_repack = value;
+	else if (n == "single_pass_encode") adac::g_tuning.single_pass_encode = value;
 	else if (n == "templated_scan") adac::g_tuning.templated_scan = value;
 	else if (n == "scan_tiles_per_wg" && value >= 0) adac::g_tuning.scan_tiles_per_wg = value; // 0 = by type
 	else if (n == "blocks_per_cu" && value > 0) adac::g_tuning.blocks_per_cu = value;
@@ -546,6 +549,9 @@ extern "C" adac_status adac_layout_create(adac_ctx *c, int type, const uint32_t 
 		const uint64_t off = val_offs ? val_offs[s] : run;
 		l->val_offs[s] = off;
 		if (off != run) l->dense_values = false;
+		if (((off & (16 / l->type_size - 1)) + (uint64_t)counts[s]) * l->type_size > adac::kEncodeOnePassBytes) {
+			l->single_pass_ok = false;
+		}
 		run = off + counts[s];
 		if (off + counts[s] > l->value_span) l->value_span = off + counts[s];
 		l->total_values += counts[s];
@@ -598,6 +604,7 @@ extern "C" void adac_layout_destroy(adac_layout *l) {
 	if (l->d_block_tot) (void)hipFree(l->d_block_tot);
 	if (l->d_group_refs) (void)hipFree(l->d_group_refs);
 	if (l->d_groups) (void)hipFree(l->d_groups);
+	if (l->d_scan_state) (void)hipFree(l->d_scan_state);
 	adac_ctx *c = l->ctx;
 	delete l;
 	ctx_release(c);
@@ -711,6 +718,21 @@ extern "C" adac_status adac_pack(adac_layout *l, const void *d_vals, const uint6
 
 extern "C" adac_status adac_encode(adac_layout *l, const void *d_vals, const uint64_t *d_validity, int rule,
                                    int pad_to_byte, uint64_t *d_words) {
+	// (4- and 8-byte types: the 1- and 2-byte instantiations spill registers — 16 data chunks per thread plus the
+	// per-row temporaries of 4 .. 16 rows — and are slower than the two-pass form until they are restructured)
+	if (l && adac::g_tuning.single_pass_encode && l->single_pass_ok &&
+	    (l->type_size >= 4 || adac::g_tuning.single_pass_encode > 1)) {
+		// one kernel, the raw column read once (adac_encode_1p.inl); same descriptors, min/max and words
+		if ((!d_vals || !d_words) && l->total_values) return ADAC_ERR_INVALID_ARGUMENT;
+		if (rule != ADAC_RULE_APPEND && rule != ADAC_RULE_RECOMPACT) return ADAC_ERR_INVALID_ARGUMENT;
+		if (!aligned16(d_vals) || !aligned16(d_words)) return ADAC_ERR_INVALID_ARGUMENT;
+		ADAC_HIP(hipSetDevice(l->ctx->device));
+		if (!l->d_scan_state) ADAC_HIP(hipMalloc(&l->d_scan_state, (l->nseg + 2) * sizeof(uint64_t)));
+		ADAC_HIP(adac::launch_encode_1p(l->ctx->stream, l->type_size, l->is_signed, l->null_bits, rule,
+		                                pad_to_byte ? 1 : 0, l->d_descs, l->nseg, d_vals, d_validity, l->d_minmax,
+		                                l->d_scan_state, d_words));
+		return descs_changed(l);
+	}
 	adac_status st = adac_analyze(l, d_vals, d_validity, rule);
 	if (st != ADAC_OK) return st;
 	st = adac_plan(l, rule, pad_to_byte);

@@ -1,0 +1,300 @@
+// adac_encode_1p.inl — single-pass encode: analyze -> width -> arena placement -> pack with the raw column read ONCE.
+// Included into adac_kernels.hip inside namespace adac::{anonymous}.
+//
+// The two reference passes (min/max, then the pack loop: column_segment.cpp:390-400 + :426-443, or the append's running
+// min/max + BitCompressFromSuccinct, succinct.cpp:286-299 + column_segment.cpp:365-376) read a segment twice; as two
+// kernels that is 2.0 GB of HBM traffic for the 1.2 GB C2 needs.  Here ONE workgroup of 1024 threads owns a whole
+// segment (<= 256 KiB of raw rows = sixteen 16-byte chunks per thread) and keeps it in REGISTERS across the phases:
+//   1. all sixteen loads of a thread are issued back to back (256 KiB in flight per CU);
+//   2. min / max under the rule (wave shuffles -> 16 partials through LDS), minmax[] written for adac_layout_get_minmax;
+//   3. width, flags, stored min: exactly k_plan's arithmetic; the segment's arena footprint is published and its
+//      arena offset obtained by a DECOUPLED LOOK-BACK over the predecessors' published footprints (one 64-bit word per
+//      segment: 2 flag bits + value), so the result is the same exclusive prefix k_plan's single-workgroup scan gives.
+//      Workgroups take their segment from a ticket counter, so every predecessor of a waiting workgroup is already
+//      running and publishes its footprint without depending on anybody: the wait always ends;
+//   4. pack from the registers: a thread's K rows -> one bit string (concat_fields) -> ds_or_b64 into a zeroed LDS
+//      image of the output words of a STAGE (as many 1024-chunk rounds as fit 48 KiB), copied out with 16-byte stores.
+// Stages cover rows [r0 * 1024 K, r1 * 1024 K): multiples of 64 rows, so a stage's bits start on a word (in fact
+// 256-byte) boundary whatever the segment's placement in the value buffer; the chunks that straddle a stage boundary
+// because of that placement (thread 0's only) and the segment's ragged tail go row by row.
+// Results are bit-identical to k_analyze + k_plan + k_pack (tests: run_encode_decode on every type, width, rule,
+// NULL mask, padded mode, with the knob "single_pass_encode" 0 and 1).
+
+constexpr int kEncThreads = 1024;
+constexpr int kEncRounds = 16;                         // 16-byte chunks per thread
+constexpr uint32_t kEncImageWords = 48 * 1024 / 8;     // LDS image of one stage's output words
+constexpr unsigned long long kScanFlagAggregate = 1ull << 62, kScanFlagPrefix = 2ull << 62, kScanValueMask = (1ull << 62) - 1;
+
+// exclusive prefix of the footprints of segments [0, seg): wave 0 of the workgroup, all 64 lanes
+__device__ __forceinline__ uint64_t lookback_exclusive(unsigned long long *state, uint32_t seg) {
+	const uint32_t lane = threadIdx.x & 63u;
+	uint64_t sum = 0;
+	int64_t hi = (int64_t)seg - 1; // nearest predecessor not yet accounted for
+	while (hi >= 0) {
+		const int64_t idx = hi - (int64_t)lane;
+		unsigned long long v = kScanFlagPrefix; // lanes before segment 0 read as "prefix 0"
+		if (idx >= 0) v = __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const uint64_t unset = __builtin_amdgcn_ballot_w64((v >> 62) == 0ull);
+		if (unset) {
+			__builtin_amdgcn_s_sleep(2); // a predecessor has not published its footprint yet
+			continue;
+		}
+		const uint64_t prefixed = __builtin_amdgcn_ballot_w64((v >> 62) == 2ull);
+		// lanes are ordered nearest predecessor first: take everything up to and including the first prefix
+		const uint32_t stop = prefixed ? (uint32_t)__ffsll((unsigned long long)prefixed) - 1u : 63u;
+		uint64_t part = lane <= stop ? (uint64_t)(v & kScanValueMask) : 0ull;
+		part = wave_sum(part);
+		sum += part;
+		if (prefixed) break;
+		hi -= 64;
+	}
+	return sum;
+}
+
+template <typename U>
+__global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__restrict__ descs,
+                                                           uint64_t *__restrict__ minmax, const U *__restrict__ vals,
+                                                           const uint64_t *__restrict__ validity, int sign_extend,
+                                                           uint64_t null_bits, int rule, int pad,
+                                                           unsigned long long *__restrict__ scan_state,
+                                                           uint32_t *__restrict__ ticket, uint64_t *__restrict__ words) {
+	constexpr int K = 16 / (int)sizeof(U);
+	constexpr uint32_t ROUND_ROWS = kEncThreads * K; // rows one round of chunks covers: a multiple of 64
+	constexpr uint32_t type_bits = 8 * sizeof(U);
+	using S = typename std::make_signed<U>::type;
+	__shared__ __attribute__((aligned(16))) unsigned long long img[kEncImageWords + 4];
+	__shared__ uint64_t pmin[kEncThreads / 64], pmax[kEncThreads / 64];
+	__shared__ uint64_t s_word_off;
+	__shared__ uint32_t s_seg;
+	const uint32_t tid = threadIdx.x;
+	if (tid == 0) s_seg = atomicAdd(ticket, 1u);
+	for (uint32_t i = tid; i < kEncImageWords + 4; i += kEncThreads) img[i] = 0ull;
+	__syncthreads();
+	const uint32_t seg = s_seg;
+	const adac_segment_desc d = descs[seg];
+	const uint32_t n = d.count;
+	const uint32_t align = (uint32_t)(d.val_off & (K - 1));
+	// 16-byte aligned; chunk c = elements [c K, c K + K).  An empty segment reads (and ignores) its own descriptor:
+	// its val_off may be the end of the value buffer
+	const U *__restrict__ base = n ? vals + (d.val_off - align) : reinterpret_cast<const U *>(descs + seg);
+	const uint32_t nchunks = (n + align + K - 1) / K;         // <= 16 * 1024 (checked by the host)
+
+	// ---- 1. the whole segment into registers.  UNCONDITIONAL loads (index clamped to the segment's last chunk): a
+	// load under a condition gets its own s_waitcnt from the compiler and the sixteen round trips would run one after
+	// the other.  A segment's first / last chunk is loaded whole: the elements before its first row belong to the
+	// previous segment, the ones after its last row lie inside the same aligned 16 bytes of the buffer; both are
+	// masked out below by their row numbers.
+	uint4 q[kEncRounds];
+	const uint32_t last_chunk = nchunks ? nchunks - 1u : 0u;
+#pragma unroll
+	for (int r = 0; r < kEncRounds; r++) {
+		const uint32_t c = (uint32_t)r * kEncThreads + tid;
+		q[r] = reinterpret_cast<const uint4 *>(base)[c < last_chunk ? c : last_chunk];
+	}
+
+	// ---- 2. min / max under the rule.  A round whose 1024 chunks all lie inside the segment (wave-uniform test; all
+	// rounds but the first of a misplaced segment and the last one) takes a body without row or NULL tests; for the
+	// types of up to 32 bits it works on the raw 32-bit patterns: the order of uint64(sign- or zero-extended x) is the
+	// unsigned order of x's own bits (negative values extend to the largest numbers), so one v_min_u32 / v_max_u32 per
+	// row does, and the result is widened once at the end.
+	uint64_t mn = ~0ull, mx = 0;
+	uint32_t mn32 = 0xffffffffu, mx32 = 0u;
+	const bool widen_signed = rule == ADAC_RULE_APPEND && sign_extend;
+#pragma unroll
+	for (int r = 0; r < kEncRounds; r++) {
+		const uint32_t round_row = (uint32_t)r * ROUND_ROWS;
+		if (round_row >= n + align) break;
+		const bool interior = !validity && round_row >= align && round_row + ROUND_ROWS - align <= n; // uniform
+		U v[K];
+		__builtin_memcpy(v, &q[r], 16);
+		if (interior) {
+#pragma unroll
+			for (int j = 0; j < K; j++) {
+				if (sizeof(U) == 8) {
+					const uint64_t x = (uint64_t)v[j]; // 64-bit T: sign extension is the identity
+					mn = x < mn ? x : mn;
+					mx = x > mx ? x : mx;
+				} else {
+					mn32 = (uint32_t)v[j] < mn32 ? (uint32_t)v[j] : mn32;
+					mx32 = (uint32_t)v[j] > mx32 ? (uint32_t)v[j] : mx32;
+				}
+			}
+		} else {
+			const uint32_t c = (uint32_t)r * kEncThreads + tid;
+			const int32_t row0 = (int32_t)(c * K) - (int32_t)align;
+			const uint32_t vbits = chunk_validity(validity, (d.val_off - align) + (uint64_t)c * K);
+#pragma unroll
+			for (int j = 0; j < K; j++) {
+				if (c >= nchunks || (uint32_t)(row0 + j) >= n) continue;
+				const bool valid = (vbits >> j) & 1u;
+				uint64_t x;
+				if (rule == ADAC_RULE_APPEND) { // succinct.cpp:286-287: uint64_t(sdata[i]); NULL rows do not take part
+					if (!valid) continue;
+					x = sign_extend ? (uint64_t)(int64_t)(S)v[j] : (uint64_t)v[j];
+				} else { // column_segment.cpp:392-399: every slot, zero-extended; NULL slots hold NullValue<T>
+					x = valid ? (uint64_t)v[j] : null_bits;
+				}
+				mn = x < mn ? x : mn;
+				mx = x > mx ? x : mx;
+			}
+		}
+	}
+	if (sizeof(U) < 8 && mn32 <= mx32) { // some interior row was seen: widen the 32-bit extrema
+		const uint64_t a = widen_signed ? (uint64_t)(int64_t)(S)(U)mn32 : (uint64_t)mn32;
+		const uint64_t b = widen_signed ? (uint64_t)(int64_t)(S)(U)mx32 : (uint64_t)mx32;
+		mn = a < mn ? a : mn;
+		mx = b > mx ? b : mx;
+	}
+	mn = wave_min(mn);
+	mx = wave_max(mx);
+	if ((tid & 63u) == 0u) {
+		pmin[tid >> 6] = mn;
+		pmax[tid >> 6] = mx;
+	}
+	__syncthreads();
+#pragma unroll
+	for (int i = 0; i < kEncThreads / 64; i++) {
+		mn = pmin[i] < mn ? pmin[i] : mn;
+		mx = pmax[i] > mx ? pmax[i] : mx;
+	}
+
+	// ---- 3. width, flags, stored min (k_plan), footprint, arena offset
+	uint32_t w = type_bits;
+	uint8_t flags = 0;
+	uint64_t stored_min = mn;
+	{
+		const uint32_t cand = width_for(mn, mx, rule, pad);
+		if (type_bits > cand) { // `if (old_width > min_width)` column_segment.cpp:363,420
+			w = cand;
+			flags = ADAC_SEG_PACKED;
+			if (mn == ~0ull && mx == ~0ull) stored_min = ~0ull - mask64(w); // sentinel collision, see k_plan
+		}
+	}
+	const uint64_t footprint = ((((uint64_t)n * w + 64) >> 6) + 15) & ~15ull; // SDSL allocation, rounded to 128 B
+	if (tid < 64) {
+		if (tid == 0) { // publish the own footprint first: successors can then pass over this segment
+			__hip_atomic_store(&scan_state[seg], (seg == 0 ? kScanFlagPrefix : kScanFlagAggregate) | footprint,
+			                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		const uint64_t excl = seg == 0 ? 0ull : lookback_exclusive(scan_state, seg);
+		if (tid == 0) {
+			if (seg != 0) {
+				__hip_atomic_store(&scan_state[seg], kScanFlagPrefix | (excl + footprint), __ATOMIC_RELAXED,
+				                   __HIP_MEMORY_SCOPE_AGENT);
+			}
+			s_word_off = excl;
+			minmax[2 * (uint64_t)seg] = mn;
+			minmax[2 * (uint64_t)seg + 1] = mx;
+			descs[seg].word_off = excl;
+			descs[seg].min = stored_min;
+			descs[seg].width = (uint8_t)w;
+			descs[seg].flags = flags;
+			descs[seg].reserved = 0;
+		}
+	}
+	__syncthreads();
+	if (n == 0) return;
+	unsigned long long *__restrict__ dst = reinterpret_cast<unsigned long long *>(words) + s_word_off;
+
+	// ---- 4. pack from the registers, stage by stage
+	const U sub = (U)(((flags & ADAC_SEG_PACKED) && stored_min != ADAC_NO_MIN) ? stored_min : 0ull); // column_segment.cpp:371-373
+	const U wmask = (U)mask64(w);
+	uint32_t rps = (kEncImageWords * 64u) / (ROUND_ROWS * w); // whole rounds per stage
+	rps = rps < 1u ? 1u : rps;
+	uint32_t stage_lo = 0; // first row of the current stage (a multiple of ROUND_ROWS)
+
+	// rows [lo, hi) of chunk (row0 .. row0 + K) -> the stage image
+	auto emit = [&](const uint4 &chunk, uint32_t c, uint32_t lo, uint32_t hi) {
+		const int32_t row0 = (int32_t)(c * K) - (int32_t)align;
+		U v[K];
+		__builtin_memcpy(v, &chunk, 16);
+		if (validity) {
+			const uint32_t vbits = chunk_validity(validity, (d.val_off - align) + (uint64_t)c * K);
+#pragma unroll
+			for (int j = 0; j < K; j++) v[j] = ((vbits >> j) & 1u) ? v[j] : (U)null_bits; // NullValue<T> (succinct.cpp:288-291)
+		}
+		const bool inside = row0 >= (int32_t)lo && (uint32_t)row0 + K <= hi;
+		if (w <= 32u) { // 32-bit emission (chunk_string32): rows outside [lo, hi) become field 0 and leave no bit
+			if (!inside) {
+#pragma unroll
+				for (int j = 0; j < K; j++) {
+					const int32_t row = row0 + j;
+					if (row < (int32_t)lo || row >= (int32_t)hi) v[j] = sub;
+				}
+			}
+			// a chunk that starts before the stage (thread 0's, by `align` rows) keeps its string position: the fields
+			// of the rows before `lo` are zero, and so are the bits they would have set — but the position must not be
+			// negative, so such a chunk goes row by row below
+			if (row0 >= (int32_t)stage_lo) {
+				const Str128 str = chunk_string32<U>(v, (uint32_t)sub, (uint32_t)wmask, w);
+				image_or32(reinterpret_cast<uint32_t *>(img), ((uint32_t)row0 - stage_lo) * w, str, (uint32_t)K * w);
+				return;
+			}
+		}
+		U f[K];
+#pragma unroll
+		for (int j = 0; j < K; j++) f[j] = (U)((U)(v[j] - sub) & wmask);
+		if (inside) {
+			uint64_t s_lo, s_hi;
+			concat_fields<U>(f, w, s_lo, s_hi);
+			image_or(img, ((uint32_t)row0 - stage_lo) * w, s_lo, s_hi);
+		} else {
+#pragma unroll
+			for (int j = 0; j < K; j++) {
+				const int32_t row = row0 + j;
+				if (row >= (int32_t)lo && row < (int32_t)hi) image_or(img, ((uint32_t)row - stage_lo) * w, (uint64_t)f[j], 0ull);
+			}
+		}
+	};
+	// the image holds rows [stage_lo, hi): out to the arena, and zero again
+	auto flush = [&](uint32_t hi) {
+		__syncthreads();
+		const uint32_t nwords = ((hi - stage_lo) * w + 63u) >> 6;
+		unsigned long long *__restrict__ out = dst + (((uint64_t)stage_lo * w) >> 6);
+		for (uint32_t i = 2u * tid; i < nwords; i += 2u * kEncThreads) {
+			const unsigned long long v0 = img[i], v1 = img[i + 1];
+			img[i] = 0ull;
+			img[i + 1] = 0ull;
+			if (i + 1 < nwords) {
+				uint4 o;
+				o.x = (uint32_t)v0;
+				o.y = (uint32_t)(v0 >> 32);
+				o.z = (uint32_t)v1;
+				o.w = (uint32_t)(v1 >> 32);
+				*reinterpret_cast<uint4 *>(out + i) = o;
+			} else {
+				out[i] = v0;
+			}
+		}
+		__syncthreads();
+	};
+	const uint32_t p_thread = (tid * K - align) * w; // bit position of this thread's chunk inside round 0 (wraps for
+	                                                  // thread 0 of a misplaced segment: that chunk goes row by row)
+#pragma unroll
+	for (int r = 0; r < kEncRounds; r++) {
+		const uint32_t round_row = (uint32_t)r * ROUND_ROWS;
+		if (round_row >= n + align) break; // uniform: no chunk of this or a later round holds a row
+		const uint32_t c = (uint32_t)r * kEncThreads + tid;
+		if (r > 0 && ((uint32_t)r % rps) == 0u && round_row < n) { // uniform: a stage ends before this round
+			// thread 0's chunk of this round starts `align` rows before the boundary: those rows belong to the stage
+			// that is about to be written out
+			if (tid == 0 && align) emit(q[r], c, stage_lo, round_row);
+			flush(round_row);
+			stage_lo = round_row;
+		}
+		const uint32_t stage_hi = stage_lo + rps * ROUND_ROWS;
+		// uniform: every chunk of the round lies inside the segment AND inside the stage (thread 0's chunk starts
+		// `align` rows before the round): no row tests, no NULLs, 32-bit emission
+		const bool interior = !validity && w <= 32u && round_row >= align && round_row + ROUND_ROWS - align <= n &&
+		                      (align == 0u || round_row > stage_lo);
+		if (interior) {
+			U v[K];
+			__builtin_memcpy(v, &q[r], 16);
+			const Str128 str = chunk_string32<U>(v, (uint32_t)sub, (uint32_t)wmask, w);
+			image_or32(reinterpret_cast<uint32_t *>(img), p_thread + (round_row - stage_lo) * w, str, (uint32_t)K * w);
+		} else if (c < nchunks) {
+			emit(q[r], c, stage_lo, stage_hi < n ? stage_hi : n);
+		}
+	}
+	flush(n);
+}

@@ -70,6 +70,7 @@ hipError_t launch_unpack_jobs(hipStream_t s, uint32_t type_size, const UnpackJob
 // workgroups are launched.  Defaults are the measured-best settings on MI355X.
 struct Tuning {
 	int persistent_unpack = 0;  // measured 5-15 % slower than one tile per workgroup (profiles/r01_ab_*.json)
+	int single_pass_encode = 1; // A/B: 0 = analyze + plan + pack as three kernels (the raw column is read twice)
 	int grouped_repack = 1;     // A/B: 0 = one tile per workgroup with the 16 KiB row image (the first version)
 	int sel_debug = 0;          // diagnostic: selection scan without its flush (1) / without any bitmap emit (2)
 	int scan_probe = 0;         // diagnostic: fused-scan loop + loads only (no field walk)
@@ -106,6 +107,12 @@ hipError_t launch_analyze_packed(hipStream_t s, uint32_t type_size, bool sign_ex
 hipError_t launch_repack(hipStream_t s, uint32_t type_size, uint64_t null_bits, const adac_segment_desc *d_src_descs,
                          const adac_segment_desc *d_dst_descs, const TileRef *d_tiles, uint64_t ntiles,
                          const uint64_t *d_src_words, const uint64_t *d_validity, uint64_t *d_dst_words);
+// single-pass encode (adac_encode_1p.inl): every segment must fit sixteen 16-byte chunks per thread of a 1024-thread
+// workgroup, counted from the 16-byte boundary at or before its first element
+constexpr uint64_t kEncodeOnePassBytes = 16ull * 1024 * 16;
+hipError_t launch_encode_1p(hipStream_t s, uint32_t type_size, bool sign_extend, uint64_t null_bits, int rule,
+                            int pad_to_byte, adac_segment_desc *d_descs, uint64_t nseg, const void *d_vals,
+                            const uint64_t *d_validity, uint64_t *d_minmax, void *d_scan_state, uint64_t *d_words);
 hipError_t launch_analyze_packed_g(hipStream_t s, uint32_t type_size, bool sign_extend, uint64_t null_bits, int rule,
                                    const ScanGroup *d_src_groups, uint64_t ngroups, const uint64_t *d_src_words,
                                    const uint64_t *d_validity, uint64_t *d_minmax);

@@ -1296,6 +1296,95 @@ __device__ __forceinline__ void image_or(unsigned long long *img, uint32_t p, ui
 	if (o2) atomicOr(&img[idx + 2], (unsigned long long)o2);
 }
 
+// ---- the same emission in 32-bit arithmetic, for destination widths <= 32 (every type; for the 8-byte types this is
+// the common case: a frame-of-reference width above 32 bits is rare).  64-bit shifts and the per-word "is it zero"
+// branches made the generic form above cost ~100 instructions per chunk — the pack phase, not HBM, bounded the
+// kernels that use it.  Here the K fields of a chunk (low dwords only: just the low w bits of x - min matter) are
+// folded to four sub-strings of wq = (K / 4) * w <= 32 bits with v_lshl_or_b32, those to a string of <= 128 bits
+// {s0..s3} with uniform funnel shifts, and the string is placed at its lane-dependent bit position with
+// v_alignbit_b32 and a fixed (wave-uniform) number of ds_or_b32.
+struct Str128 {
+	uint32_t s0, s1, s2, s3;
+};
+
+// (hi:lo) << t for a UNIFORM t in 0..32, as {d0, d1, d2}
+__device__ __forceinline__ void shl64_u(uint32_t lo, uint32_t hi, uint32_t t, uint32_t &d0, uint32_t &d1, uint32_t &d2) {
+	if (t == 0u) {
+		d0 = lo, d1 = hi, d2 = 0u;
+	} else if (t == 32u) {
+		d0 = 0u, d1 = lo, d2 = hi;
+	} else {
+		d0 = lo << t;
+		d1 = __builtin_amdgcn_alignbit(hi, lo, 32u - t);
+		d2 = hi >> (32u - t);
+	}
+}
+
+// four sub-strings of wq bits each (uniform wq in 1..32) -> their 4 * wq-bit concatenation
+__device__ __forceinline__ Str128 concat4(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t wq) {
+	// pairs (a, b) and (c, d): 2 * wq <= 64 bits each
+	uint32_t p0, p1, q0, q1, x;
+	shl64_u(b, 0u, wq, p0, p1, x);
+	p0 |= a;
+	shl64_u(d, 0u, wq, q0, q1, x);
+	q0 |= c;
+	// (q1:q0) << 2 * wq, 2 * wq in 2..64
+	Str128 r;
+	const uint32_t t = 2u * wq;
+	if (t <= 32u) {
+		uint32_t d0, d1, d2;
+		shl64_u(q0, q1, t, d0, d1, d2);
+		r.s0 = p0 | d0, r.s1 = p1 | d1, r.s2 = d2, r.s3 = 0u;
+	} else {
+		uint32_t d0, d1, d2;
+		shl64_u(q0, q1, t - 32u, d0, d1, d2);
+		r.s0 = p0, r.s1 = p1 | d0, r.s2 = d1, r.s3 = d2;
+	}
+	return r;
+}
+
+// the chunk's K values (x[j] = value or NullValue, already chosen) -> (x - sub) & mask fields -> one string.
+// w <= 32 and uniform.  sub32 / mask32: low dwords of the frame of reference and of the width mask.
+template <typename U>
+__device__ __forceinline__ Str128 chunk_string32(const U *x, uint32_t sub32, uint32_t mask32, uint32_t w) {
+	constexpr int K = 16 / (int)sizeof(U);
+	uint32_t f[K];
+#pragma unroll
+	for (int j = 0; j < K; j++) f[j] = ((uint32_t)x[j] - sub32) & mask32;
+	if (K == 2) {
+		uint32_t d0, d1, d2;
+		shl64_u(f[1], 0u, w, d0, d1, d2);
+		return Str128 {d0 | f[0], d1, 0u, 0u};
+	}
+	uint32_t q[4];
+	if (K == 4) {
+#pragma unroll
+		for (int i = 0; i < 4; i++) q[i] = f[i];
+	} else if (K == 8) { // w <= 16: a pair fits a dword
+#pragma unroll
+		for (int i = 0; i < 4; i++) q[i] = f[2 * i] | (f[2 * i + 1] << w);
+	} else { // K == 16, w <= 8
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			q[i] = f[4 * i] | (f[4 * i + 1] << w) | (f[4 * i + 2] << (2u * w)) | (f[4 * i + 3] << (3u * w));
+		}
+	}
+	return concat4(q[0], q[1], q[2], q[3], (uint32_t)(K / 4) * w);
+}
+
+// OR a string of `nbits` bits (uniform, <= 128) into the zeroed 32-bit word image at bit position p (per lane)
+__device__ __forceinline__ void image_or32(uint32_t *img32, uint32_t p, const Str128 &s, uint32_t nbits) {
+	const uint32_t idx = p >> 5, sh = p & 31u, rs = 32u - sh;
+	const bool z = sh == 0u; // v_alignbit takes its shift mod 32: a shift of 32 must be patched
+	atomicOr(&img32[idx], s.s0 << sh);
+	if (nbits > 1u) { // the string may reach the next word (nbits + sh > 32 for some lane)
+		atomicOr(&img32[idx + 1], z ? s.s1 : __builtin_amdgcn_alignbit(s.s1, s.s0, rs));
+	}
+	if (nbits > 33u) atomicOr(&img32[idx + 2], z ? s.s2 : __builtin_amdgcn_alignbit(s.s2, s.s1, rs));
+	if (nbits > 65u) atomicOr(&img32[idx + 3], z ? s.s3 : __builtin_amdgcn_alignbit(s.s3, s.s2, rs));
+	if (nbits > 97u) atomicOr(&img32[idx + 4], z ? 0u : (s.s3 >> rs));
+}
+
 // whole tiles of a stage: both packed sides within 16 KiB
 template <typename U>
 __device__ __forceinline__ uint32_t stage_tiles(uint32_t w_a, uint32_t w_b) {
@@ -1338,6 +1427,16 @@ __global__ __launch_bounds__(kWorkgroup) void k_repack_g(const ScanGroup *__rest
 			const uint32_t rest = n - (uint32_t)base;
 			const uint32_t rows_here = full || rest >= (uint32_t)K ? (uint32_t)K : rest;
 			const uint32_t vbits = validity ? validity_window(validity, elem0 + (uint32_t)base, rows_here) : 0xffffffffu;
+			if (w <= 32u) { // 32-bit emission (see chunk_string32)
+				U x[K];
+#pragma unroll
+				for (int j = 0; j < K; j++) { // rows past the run leave no bit: x = sub gives field 0
+					x[j] = (uint32_t)j < rows_here ? (((vbits >> j) & 1u) ? v[j] : (U)null_bits) : sub;
+				}
+				const Str128 str = chunk_string32<U>(x, (uint32_t)sub, (uint32_t)wmask, w);
+				image_or32(reinterpret_cast<uint32_t *>(img), (uint32_t)base * w, str, (uint32_t)K * w);
+				return;
+			}
 			U f[K];
 #pragma unroll
 			for (int j = 0; j < K; j++) {
@@ -1482,6 +1581,7 @@ hipError_t dispatch_size(uint32_t type_size, F &&f) {
 #include "adac_bitpacking.inl"
 #include "adac_select_gather.inl"
 #include "adac_block_image.inl"
+#include "adac_encode_1p.inl"
 
 unsigned persistent_grid(uint64_t ntiles) {
 	const uint64_t cap = (uint64_t)g_tuning.num_cus * (uint64_t)g_tuning.blocks_per_cu;
@@ -1550,6 +1650,23 @@ hipError_t launch_repack(hipStream_t s, uint32_t type_size, uint64_t null_bits, 
 		using U = decltype(tag);
 		hipLaunchKernelGGL(k_repack<U>, dim3((unsigned)ntiles), dim3(kWorkgroup), 0, s, d_src_descs, d_dst_descs,
 		                   d_tiles, d_src_words, d_validity, null_bits, d_dst_words);
+		return hipGetLastError();
+	});
+}
+
+hipError_t launch_encode_1p(hipStream_t s, uint32_t type_size, bool sign_extend, uint64_t null_bits, int rule,
+                            int pad_to_byte, adac_segment_desc *d_descs, uint64_t nseg, const void *d_vals,
+                            const uint64_t *d_validity, uint64_t *d_minmax, void *d_scan_state, uint64_t *d_words) {
+	if (nseg == 0) return hipSuccess;
+	// scan_state: nseg look-back words followed by the ticket counter, all zero before the launch
+	hipError_t e = hipMemsetAsync(d_scan_state, 0, (nseg + 1) * sizeof(unsigned long long), s);
+	if (e != hipSuccess) return e;
+	return dispatch_size(type_size, [&](auto tag) {
+		using U = decltype(tag);
+		unsigned long long *state = static_cast<unsigned long long *>(d_scan_state);
+		hipLaunchKernelGGL(k_encode_1p<U>, dim3((unsigned)nseg), dim3(kEncThreads), 0, s, d_descs, d_minmax,
+		                   static_cast<const U *>(d_vals), d_validity, sign_extend ? 1 : 0, null_bits, rule, pad_to_byte,
+		                   state, reinterpret_cast<uint32_t *>(state + nseg), d_words);
 		return hipGetLastError();
 	});
 }
