@@ -5,7 +5,12 @@
 // min/max + BitCompressFromSuccinct, succinct.cpp:286-299 + column_segment.cpp:365-376) read a segment twice; as two
 // kernels that is 2.0 GB of HBM traffic for the 1.2 GB C2 needs.  Here ONE workgroup of 1024 threads owns a whole
 // segment (<= 256 KiB of raw rows = sixteen 16-byte chunks per thread) and keeps it in REGISTERS across the phases:
-//   1. all sixteen loads of a thread are issued back to back (256 KiB in flight per CU);
+//   1. all sixteen loads of a thread are issued back to back (256 KiB in flight per CU).  A segment fills half of a
+//      CU's register file, so there is ONE workgroup per CU and its load phase cannot overlap another workgroup's
+//      compute phase: the kernel alternates between them, which is why it gains 9 % on the three-kernel form (0.33 vs
+//      0.36 ms at C2) and not the 40 % the byte count promises.  A persistent form that hands a packed round's
+//      registers to the next segment's loads was built and measured SLOWER (0.40 ms): the compiler spills two of the
+//      sixteen chunks under the extra pressure, and every scratch reload waits for all loads in flight;
 //   2. min / max under the rule (wave shuffles -> 16 partials through LDS), minmax[] written for adac_layout_get_minmax;
 //   3. width, flags, stored min: exactly k_plan's arithmetic; the segment's arena footprint is published and its
 //      arena offset obtained by a DECOUPLED LOOK-BACK over the predecessors' published footprints (one 64-bit word per
@@ -49,6 +54,13 @@ __device__ __forceinline__ uint64_t lookback_exclusive(unsigned long long *state
 		hi -= 64;
 	}
 	return sum;
+}
+
+// a value every lane holds alike, moved to scalar registers (the builtin returns int: mind the sign)
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) {
+	const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
+	const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+	return ((uint64_t)hi << 32) | lo;
 }
 
 template <typename U>
@@ -157,6 +169,10 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 		mn = pmin[i] < mn ? pmin[i] : mn;
 		mx = pmax[i] > mx ? pmax[i] : mx;
 	}
+	// every thread now holds the same pair: tell the compiler (everything derived from it — width, masks, stage
+	// geometry — then lives in scalar registers instead of costing a vector register per thread)
+	mn = uniform64(mn);
+	mx = uniform64(mx);
 
 	// ---- 3. width, flags, stored min (k_plan), footprint, arena offset
 	uint32_t w = type_bits;
@@ -194,7 +210,7 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 	}
 	__syncthreads();
 	if (n == 0) return;
-	unsigned long long *__restrict__ dst = reinterpret_cast<unsigned long long *>(words) + s_word_off;
+	unsigned long long *__restrict__ dst = reinterpret_cast<unsigned long long *>(words) + uniform64(s_word_off);
 
 	// ---- 4. pack from the registers, stage by stage
 	const U sub = (U)(((flags & ADAC_SEG_PACKED) && stored_min != ADAC_NO_MIN) ? stored_min : 0ull); // column_segment.cpp:371-373
