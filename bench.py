@@ -438,8 +438,9 @@ def main():
     result["encode"] = {
         "values_per_s": my_rows / (enc_ms * 1e-3), "ms": enc_ms,
         "algorithmic_GBps": (2 * wr + rd) / (enc_ms * 1e-3) / 1e9,
-        "note": "analyze + plan + pack, raw column read twice (min/max pass, pack pass): BitCompressFromUncompressed's "
-                "two passes (column_segment.cpp:385-456)",
+        "note": "adac_encode: single-pass kernel (k_encode_1p: a segment stays in the registers of one workgroup across "
+                "min/max, width, arena placement and pack; the raw column is read once) for 4- and 8-byte types; "
+                "BitCompressFromUncompressed's two passes (column_segment.cpp:385-456) in one",
         "compact_after_append": {
             "ms": pack_ms, "values_per_s": my_rows / (pack_ms * 1e-3),
             "algorithmic_GBps": (wr + rd) / (pack_ms * 1e-3) / 1e9,
@@ -467,7 +468,8 @@ def main():
         result["fused_scan"]["select_bitmap"] = {
             "kernel": "k_scan_agg<u64,select>", "values_per_s": my_rows / (ms_sel * 1e-3), "ms": ms_sel,
             "read_GBps": rd / (ms_sel * 1e-3) / 1e9, "bitmap_bytes": (my_rows + 7) // 8,
-            "note": "includes clearing the bitmap (hipMemsetAsync) before the kernel",
+            "note": "includes the tiny kernel that zeroes the bitmap words two scan groups share (no full clearing pass: "
+                    "the scan writes every other word whole)",
         }
         # scan-with-selection: decode only the rows the bitmap keeps (dense output + element ids)
         nsel = int((vals <= median).sum())

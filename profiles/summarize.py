@@ -25,7 +25,8 @@ def one(pattern):
 
 
 def short(name):
-    for k in ("k_unpack", "k_scan_agg", "k_pack", "k_analyze", "k_plan", "k_minmax_init", "k_fetch"):
+    for k in ("k_unpack_jobs", "k_unpack", "k_scan_agg", "k_encode_1p", "k_sel_clear_edges", "k_gather", "k_pack",
+              "k_analyze", "k_plan", "k_minmax_init", "k_fetch"):
         if k in name:
             if "unsigned long" in name:
                 t = "u64"
