@@ -25,7 +25,8 @@ nthreads = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 errors = []
 for run, cache in enumerate((0, 16 << 20)):
     rng = np.random.default_rng(100 + run)
-    db = host.Database(0, adaptive=True, arena_bytes=128 << 20, decoded_cache_bytes=cache)
+    pools = int(os.environ.get("SOAK_POOLS", "1"))   # several segment pools (all on the one GPU of the box)
+    db = host.Database([0] * pools, adaptive=True, arena_bytes=128 << 20, decoded_cache_bytes=cache)
     cols = []
     for i in range(24):
         dtype = (np.uint32, np.int64, np.uint16)[i % 3]
