@@ -82,8 +82,10 @@ def adaptive(host, wl, nseg=400, rows=32767, periods=4):
     rng = np.random.default_rng(3)
     out = {"segments": nseg, "rows_per_segment": rows, "skews": {}}
     data = [((i << 34) + rng.integers(0, 1 << (10 + i % 12), size=rows)).astype(np.uint64) for i in range(nseg)]
-    for skew in (0.5, 1.0, 2.0):
-        db = host.Database(0, adaptive=True, arena_bytes=512 << 20)
+    for skew, cache in ((0.5, 0), (1.0, 0), (2.0, 0), (0.5, 128 << 20)):
+        # the last variant keeps decoded images of the packed segments it touches in the page-locked cache: a
+        # look-up into a packed segment is then a memcpy, not a device round trip
+        db = host.Database(0, adaptive=True, arena_bytes=512 << 20, decoded_cache_bytes=cache, prefetch_segments=1)
         db.reserve_staging(nseg * rows * 8 + (1 << 20))   # one-time page-locking kept out of the first policy round
         for i in range(nseg):
             s = db.create_segment(np.uint64, start=i * rows)
@@ -111,7 +113,7 @@ def adaptive(host, wl, nseg=400, rows=32767, periods=4):
                 "policy_step_s": t_policy, "segments_packed": packed, "segments_expanded": expanded,
                 "reencode_raw_GBps": (packed + expanded) * rows * 8 / t_policy / 1e9 if t_policy > 0 else None,
             })
-        out["skews"][str(skew)] = rec
+        out["skews"][str(skew) + ("_decoded_cache" if cache else "")] = rec
         db.close()
     return out
 
