@@ -1394,16 +1394,162 @@ __device__ __forceinline__ uint32_t stage_tiles(uint32_t w_a, uint32_t w_b) {
 	return fit < 1u ? 1u : fit;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Width-templated source walk of the re-compaction (4 <= old_w <= 32, new_w <= 32, no NULL mask): the fused scans'
+// chunk walk — a lane owns whole 16-byte chunks of the SOURCE stream and finds every field at a compile-time
+// position (one v_bfe each, no LDS staging, no per-row address arithmetic) — feeding a streaming emission: the fields
+// of a chunk are consecutive rows, so their re-based values form ONE bit string of have * new_w bits; it is built in a
+// 64-bit accumulator at wave-uniform offsets (scalar bookkeeping), and every completed dword is shifted to the
+// lane's own bit position with one v_alignbit and ORed into the zeroed LDS image of the stage's output words.
+// The generic form read every row back from an LDS image (address arithmetic + two ds_read + funnel + mask + add
+// per row: 26 vector instructions per row at 8 bits, 75 of 87 us) — this one spends ~8.
+// ---------------------------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ void repack_run_w(const uint4 *__restrict__ seg16, uint32_t r0, uint32_t r1, uint32_t count,
+                                             uint32_t delta, uint32_t w_new, uint32_t *img32) {
+	constexpr int MAXV = (128 + W - 1) / W;
+	const uint32_t mask_new = w_new >= 32u ? 0xffffffffu : ((1u << w_new) - 1u);
+	const uint32_t c0 = (uint32_t)(((uint64_t)r0 * W) >> 7); // r0 is a multiple of 128 rows
+	const uint32_t c1 = (uint32_t)(((uint64_t)r1 * W + 127) >> 7);
+	const uint32_t clast = (uint32_t)(((uint64_t)count * W + 127) >> 7) - 1; // last chunk holding data bits
+	uint32_t L = c0 + threadIdx.x;
+	if (L >= c1) return;
+	const uint32_t Lc = L < clast ? L : clast;
+	uint4 q = seg16[Lc];
+	uint32_t e = reinterpret_cast<const uint32_t *>(seg16 + (Lc < clast ? Lc + 1 : clast))[0];
+	for (; L < c1; L += kWorkgroup) {
+		const uint32_t Lp = L + kWorkgroup < clast ? L + kWorkgroup : clast;
+		const uint4 qn = seg16[Lp];
+		const uint32_t en = reinterpret_cast<const uint32_t *>(seg16 + (Lp < clast ? Lp + 1 : clast))[0];
+		const uint32_t i0 = (128u * L + (W - 1)) / W; // first row starting in this chunk
+		const uint32_t o0 = i0 * W - 128u * L;        // its bit offset, < W <= 32
+		uint32_t nrm[5];
+		nrm[0] = __builtin_amdgcn_alignbit(q.y, q.x, o0);
+		nrm[1] = __builtin_amdgcn_alignbit(q.z, q.y, o0);
+		nrm[2] = __builtin_amdgcn_alignbit(q.w, q.z, o0);
+		nrm[3] = __builtin_amdgcn_alignbit(e, q.w, o0);
+		nrm[4] = e >> o0;
+		q = qn;
+		e = en;
+		const uint32_t starting = (128u - o0 + (W - 1)) / W; // rows starting in the chunk: MAXV-1 or MAXV
+		const uint32_t lim = r1 > i0 ? r1 - i0 : 0u;
+		const uint32_t have = starting < lim ? starting : lim;
+		if (have == 0u) continue;
+		// the string starts at bit p of the stage image; dwords leave through a funnel by p's offset in its dword
+		const uint32_t p = (i0 - r0) * w_new;
+		uint32_t *out = img32 + (p >> 5);
+		const uint32_t sh = p & 31u, rs = 32u - sh;
+		const bool z = sh == 0u;
+		uint64_t acc = 0;
+		uint32_t prev = 0;
+		uint32_t t = 0, nd = 0; // wave-uniform: bits in acc, dwords emitted
+#pragma unroll
+		for (int j = 0; j < MAXV; j++) {
+			const uint32_t g = (uint32_t)j < have ? ((field_of<W>(nrm, j) + delta) & mask_new) : 0u;
+			acc |= (uint64_t)g << t;
+			t += w_new;
+			if (t >= 32u) { // uniform
+				const uint32_t cur = (uint32_t)acc;
+				atomicOr(&out[nd], z ? cur : __builtin_amdgcn_alignbit(cur, prev, rs));
+				prev = cur;
+				acc >>= 32;
+				t -= 32u;
+				nd++;
+			}
+		}
+		const uint32_t cur = (uint32_t)acc; // the last, partial dword (zero when t == 0) and what the funnel still holds
+		atomicOr(&out[nd], z ? cur : __builtin_amdgcn_alignbit(cur, prev, rs));
+		if (!z) atomicOr(&out[nd + 1], cur >> rs);
+	}
+}
+
+// The same source walk for the min / max pass of a re-compaction: the extrema of the rows' T-bit patterns
+// x = (field + old min) mod 2^(8 sizeof T), in unsigned order (which IS the order of the sign- or zero-extended 64-bit
+// values both rules compare: negative values extend to the largest numbers).  Types of up to 32 bits track x itself;
+// the 8-byte types track the field (a packed 8-byte segment never wraps mod 2^64: a mixed-sign range needs 64 bits and
+// stays unpacked) and add the old min once at the end.
+template <int W, int TBITS>
+__device__ __forceinline__ void analyze_run_w(const uint4 *__restrict__ seg16, uint32_t r0, uint32_t r1, uint32_t count,
+                                              uint32_t add32, uint32_t &mn32, uint32_t &mx32) {
+	constexpr int MAXV = (128 + W - 1) / W;
+	constexpr uint32_t tmask = TBITS >= 32 ? 0xffffffffu : ((1u << (TBITS & 31)) - 1u);
+	const uint32_t c0 = (uint32_t)(((uint64_t)r0 * W) >> 7);
+	const uint32_t c1 = (uint32_t)(((uint64_t)r1 * W + 127) >> 7);
+	const uint32_t clast = (uint32_t)(((uint64_t)count * W + 127) >> 7) - 1;
+	uint32_t L = c0 + threadIdx.x;
+	if (L >= c1) return;
+	const uint32_t Lc = L < clast ? L : clast;
+	uint4 q = seg16[Lc];
+	uint32_t e = reinterpret_cast<const uint32_t *>(seg16 + (Lc < clast ? Lc + 1 : clast))[0];
+	for (; L < c1; L += kWorkgroup) {
+		const uint32_t Lp = L + kWorkgroup < clast ? L + kWorkgroup : clast;
+		const uint4 qn = seg16[Lp];
+		const uint32_t en = reinterpret_cast<const uint32_t *>(seg16 + (Lp < clast ? Lp + 1 : clast))[0];
+		const uint32_t i0 = (128u * L + (W - 1)) / W;
+		const uint32_t o0 = i0 * W - 128u * L;
+		uint32_t nrm[5];
+		nrm[0] = __builtin_amdgcn_alignbit(q.y, q.x, o0);
+		nrm[1] = __builtin_amdgcn_alignbit(q.z, q.y, o0);
+		nrm[2] = __builtin_amdgcn_alignbit(q.w, q.z, o0);
+		nrm[3] = __builtin_amdgcn_alignbit(e, q.w, o0);
+		nrm[4] = e >> o0;
+		q = qn;
+		e = en;
+		const uint32_t starting = (128u - o0 + (W - 1)) / W;
+		const uint32_t lim = r1 > i0 ? r1 - i0 : 0u;
+		const uint32_t have = starting < lim ? starting : lim;
+#pragma unroll
+		for (int j = 0; j < MAXV; j++) {
+			if ((uint32_t)j < have) {
+				const uint32_t x = TBITS == 64 ? field_of<W>(nrm, j) : ((field_of<W>(nrm, j) + add32) & tmask);
+				mn32 = x < mn32 ? x : mn32;
+				mx32 = x > mx32 ? x : mx32;
+			}
+		}
+	}
+}
+
+template <typename U>
+__device__ __forceinline__ void analyze_run_dispatch(uint32_t w_old, const uint4 *__restrict__ seg16, uint32_t r0,
+                                                     uint32_t r1, uint32_t count, uint32_t add32, uint32_t &mn32,
+                                                     uint32_t &mx32) {
+	switch (w_old) {
+#define ADAC_W(N) case N: analyze_run_w<N, 8 * (int)sizeof(U)>(seg16, r0, r1, count, add32, mn32, mx32); break;
+		ADAC_W(4) ADAC_W(5) ADAC_W(6) ADAC_W(7) ADAC_W(8) ADAC_W(9) ADAC_W(10) ADAC_W(11) ADAC_W(12) ADAC_W(13)
+		ADAC_W(14) ADAC_W(15) ADAC_W(16) ADAC_W(17) ADAC_W(18) ADAC_W(19) ADAC_W(20) ADAC_W(21) ADAC_W(22)
+		ADAC_W(23) ADAC_W(24) ADAC_W(25) ADAC_W(26) ADAC_W(27) ADAC_W(28) ADAC_W(29) ADAC_W(30) ADAC_W(31) ADAC_W(32)
+#undef ADAC_W
+	default: break;
+	}
+}
+
+template <typename U>
+__device__ __forceinline__ void repack_run_dispatch(uint32_t w_old, const uint4 *__restrict__ seg16, uint32_t r0,
+                                                    uint32_t r1, uint32_t count, uint32_t delta, uint32_t w_new,
+                                                    uint32_t *img32) {
+	switch (w_old) {
+#define ADAC_W(N) case N: repack_run_w<N>(seg16, r0, r1, count, delta, w_new, img32); break;
+		ADAC_W(4) ADAC_W(5) ADAC_W(6) ADAC_W(7) ADAC_W(8) ADAC_W(9) ADAC_W(10) ADAC_W(11) ADAC_W(12) ADAC_W(13)
+		ADAC_W(14) ADAC_W(15) ADAC_W(16) ADAC_W(17) ADAC_W(18) ADAC_W(19) ADAC_W(20) ADAC_W(21) ADAC_W(22)
+		ADAC_W(23) ADAC_W(24) ADAC_W(25) ADAC_W(26) ADAC_W(27) ADAC_W(28) ADAC_W(29) ADAC_W(30) ADAC_W(31) ADAC_W(32)
+#undef ADAC_W
+	default: break;
+	}
+}
+
 template <typename U>
 __global__ __launch_bounds__(kWorkgroup) void k_repack_g(const ScanGroup *__restrict__ src_groups,
                                                          const adac_segment_desc *__restrict__ dst_descs,
                                                          const uint64_t *__restrict__ src_words,
                                                          const uint64_t *__restrict__ validity, uint64_t null_bits,
-                                                         uint64_t *__restrict__ dst_words) {
-	constexpr uint32_t TILE = kTileBytes / sizeof(U);
+                                                         int templated, uint64_t *__restrict__ dst_words) {
 	constexpr int K = 16 / (int)sizeof(U);
+	constexpr uint32_t PER_ROUND = kWorkgroup * K; // rows one decode round of the workgroup covers
 	constexpr uint32_t kImgWords = kTileBytes / 8 + 4;
-	__shared__ uint4 lds[kTileBytes / 16 + 2];
+	// the generic path's staged source: 8 KiB, so that stage + image stay under 25 KiB and six workgroups fit a CU
+	// (the register path uses only the image, and is bound by the bytes a CU keeps in flight)
+	constexpr uint32_t kStageBytes = kTileBytes / 2;
+	__shared__ uint4 lds[kStageBytes / 16 + 2];
 	__shared__ __attribute__((aligned(16))) unsigned long long img[kImgWords];
 	const ScanGroup g = src_groups[blockIdx.x];
 	const adac_segment_desc &sd = g.d;
@@ -1413,13 +1559,43 @@ __global__ __launch_bounds__(kWorkgroup) void k_repack_g(const ScanGroup *__rest
 	const U sub = (U)((packed && dd.min != ADAC_NO_MIN) ? dd.min : 0ull); // column_segment.cpp:371-373
 	const U wmask = (U)mask64(w);
 	const uint64_t add = effective_add(sd);
-	const uint32_t fit = stage_tiles<U>(w_old, w);
 	for (uint32_t i = threadIdx.x; i < kImgWords; i += kWorkgroup) img[i] = 0ull;
+	if (templated && !validity && w_old >= 4u && w_old <= 32u && w <= 32u && (uint64_t)sd.count * w_old < (1ull << 31)) {
+		// register path (repack_run_w): only the low 32 bits of (field + old min - new min) matter at new_w <= 32,
+		// and they are right for every T (the value is formed mod 2^(8 sizeof T) >= 2^new_w)
+		const uint32_t delta = (uint32_t)add - (uint32_t)sub;
+		const uint4 *seg16 = reinterpret_cast<const uint4 *>(src_words + sd.word_off);
+		uint32_t stage_rows = ((8u * kTileBytes) / w) & ~127u; // output bits of a stage fit the 16 KiB image
+		__syncthreads();
+		for (uint32_t done = 0; done < g.n; done += stage_rows) {
+			const uint32_t r0 = g.first + done; // a multiple of 128 rows: chunk- and word-aligned on both sides
+			const uint32_t n = g.n - done < stage_rows ? g.n - done : stage_rows;
+			repack_run_dispatch<U>(w_old, seg16, r0, r0 + n, sd.count, delta, w, reinterpret_cast<uint32_t *>(img));
+			__syncthreads();
+			const uint32_t nwords = (n * w + 63u) >> 6;
+			unsigned long long *__restrict__ dst =
+			    reinterpret_cast<unsigned long long *>(dst_words) + dd.word_off + (((uint64_t)r0 * w) >> 6);
+			for (uint32_t q = 2u * threadIdx.x; q < nwords; q += 2u * kWorkgroup) {
+				const uint4 o = *reinterpret_cast<const uint4 *>(&img[q]);
+				*reinterpret_cast<uint4 *>(&img[q]) = make_uint4(0u, 0u, 0u, 0u);
+				if (q + 1 < nwords) {
+					*reinterpret_cast<uint4 *>(dst + q) = o;
+				} else {
+					dst[q] = ((unsigned long long)o.y << 32) | o.x;
+				}
+			}
+			__syncthreads();
+		}
+		return;
+	}
 	const uint32_t *lds32 = reinterpret_cast<const uint32_t *>(lds);
+	// stages of whole decode rounds whose packed bits fit 8 KiB on both sides (a round of 64-bit fields is 4 KiB)
+	uint32_t stage_rows = ((8u * kStageBytes) / (w_old > w ? w_old : w)) / PER_ROUND * PER_ROUND;
+	stage_rows = stage_rows < PER_ROUND ? PER_ROUND : stage_rows;
 	for (uint32_t done = 0; done < g.n;) {
-		const uint32_t first = g.first + done; // a multiple of TILE: both bit streams start on a 256-byte boundary
+		const uint32_t first = g.first + done; // a multiple of PER_ROUND rows: both bit streams start on a 16-byte boundary
 		const uint32_t left = g.n - done;
-		const uint32_t n = left < fit * TILE ? left : fit * TILE;
+		const uint32_t n = left < stage_rows ? left : stage_rows;
 		const uint32_t bit0 = stage_packed(src_words + sd.word_off, first, n, w_old, lds);
 		__syncthreads(); // the staged bits are visible; the image is zero (start, or the previous copy-out)
 		const uint64_t elem0 = sd.val_off + first;
@@ -1480,7 +1656,7 @@ __global__ __launch_bounds__(kWorkgroup) void k_analyze_packed_g(const ScanGroup
                                                                  const uint64_t *__restrict__ src_words,
                                                                  const uint64_t *__restrict__ validity,
                                                                  int sign_extend, uint64_t null_bits, int rule,
-                                                                 uint64_t *__restrict__ minmax) {
+                                                                 int templated, uint64_t *__restrict__ minmax) {
 	constexpr uint32_t TILE = kTileBytes / sizeof(U);
 	using S = typename std::make_signed<U>::type;
 	__shared__ uint4 lds[kTileBytes / 16 + 2];
@@ -1492,7 +1668,26 @@ __global__ __launch_bounds__(kWorkgroup) void k_analyze_packed_g(const ScanGroup
 	const uint32_t fit = stage_tiles<U>(w_old, w_old);
 	const uint32_t *lds32 = reinterpret_cast<const uint32_t *>(lds);
 	uint64_t mn = ~0ull, mx = 0;
-	for (uint32_t done = 0; done < g.n;) {
+	const bool reg_path = templated && !validity && w_old >= 4u && w_old <= 32u && (uint64_t)sd.count * w_old < (1ull << 31);
+	if (reg_path) { // width-templated source walk (analyze_run_w), no LDS staging
+		uint32_t mn32 = 0xffffffffu, mx32 = 0u;
+		analyze_run_dispatch<U>(w_old, reinterpret_cast<const uint4 *>(src_words + sd.word_off), g.first, g.first + g.n,
+		                        sd.count, (uint32_t)add, mn32, mx32);
+		if (mn32 <= mx32) { // this lane saw a row
+			uint64_t a, b;
+			if (sizeof(U) == 8) {
+				a = (uint64_t)mn32 + add;
+				b = (uint64_t)mx32 + add;
+			} else {
+				const bool sx = rule == ADAC_RULE_APPEND && sign_extend;
+				a = sx ? (uint64_t)(int64_t)(S)(U)mn32 : (uint64_t)mn32;
+				b = sx ? (uint64_t)(int64_t)(S)(U)mx32 : (uint64_t)mx32;
+			}
+			mn = a;
+			mx = b;
+		}
+	}
+	for (uint32_t done = reg_path ? g.n : 0u; done < g.n;) {
 		const uint32_t first = g.first + done;
 		const uint32_t left = g.n - done;
 		const uint32_t n = left < fit * TILE ? left : fit * TILE;
@@ -1678,7 +1873,7 @@ hipError_t launch_analyze_packed_g(hipStream_t s, uint32_t type_size, bool sign_
 	return dispatch_size(type_size, [&](auto tag) {
 		using U = decltype(tag);
 		hipLaunchKernelGGL(k_analyze_packed_g<U>, dim3((unsigned)ngroups), dim3(kWorkgroup), 0, s, d_src_groups,
-		                   d_src_words, d_validity, sign_extend ? 1 : 0, null_bits, rule, d_minmax);
+		                   d_src_words, d_validity, sign_extend ? 1 : 0, null_bits, rule, g_tuning.templated_scan, d_minmax);
 		return hipGetLastError();
 	});
 }
@@ -1690,7 +1885,7 @@ hipError_t launch_repack_g(hipStream_t s, uint32_t type_size, uint64_t null_bits
 	return dispatch_size(type_size, [&](auto tag) {
 		using U = decltype(tag);
 		hipLaunchKernelGGL(k_repack_g<U>, dim3((unsigned)ngroups), dim3(kWorkgroup), 0, s, d_src_groups, d_dst_descs,
-		                   d_src_words, d_validity, null_bits, d_dst_words);
+		                   d_src_words, d_validity, null_bits, g_tuning.templated_scan, d_dst_words);
 		return hipGetLastError();
 	});
 }

@@ -86,6 +86,8 @@ def main():
             rd_pad = int(((pd["count"].astype(np.uint64) * pd["width"] + 63) // 64 * 8).sum())
             timed("repack", lambda: pad.repack(d_pad, exact, d_exact))
             rec["repack_GBps"] = (rd_pad + rd) / (rec["ms"]["repack"] * 1e-3) / 1e9
+            timed("reencode", lambda: pad.reencode(d_pad, exact, d_exact, None, adac.RULE_APPEND, False))
+            rec["reencode_values_per_s"] = rows / (rec["ms"]["reencode"] * 1e-3)
             del pad, d_pad, exact, d_exact
         out.append(rec)
         del lay, d_words, d_res
