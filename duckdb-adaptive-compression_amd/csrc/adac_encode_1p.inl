@@ -63,6 +63,19 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v) {
 	return ((uint64_t)hi << 32) | lo;
 }
 
+// N consecutive dwords to a dword-aligned address as ONE store instruction (the segment's first row may sit in the
+// middle of an aligned pair, so the address is not N-dword aligned in general; the device runs in unaligned access mode)
+template <int N>
+__device__ __forceinline__ void store_dwords(uint32_t *p, const uint32_t *s) {
+	struct __attribute__((packed, aligned(4))) Pack {
+		uint32_t d[N];
+	};
+	Pack v;
+#pragma unroll
+	for (int i = 0; i < N; i++) v.d[i] = s[i];
+	*reinterpret_cast<Pack *>(p) = v;
+}
+
 template <typename U>
 __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__restrict__ descs,
                                                            uint64_t *__restrict__ minmax, const U *__restrict__ vals,
@@ -80,7 +93,6 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 	__shared__ uint32_t s_seg;
 	const uint32_t tid = threadIdx.x;
 	if (tid == 0) s_seg = atomicAdd(ticket, 1u);
-	for (uint32_t i = tid; i < kEncImageWords + 4; i += kEncThreads) img[i] = 0ull;
 	__syncthreads();
 	const uint32_t seg = s_seg;
 	const adac_segment_desc d = descs[seg];
@@ -103,6 +115,8 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 		const uint32_t c = (uint32_t)r * kEncThreads + tid;
 		q[r] = reinterpret_cast<const uint4 *>(base)[c < last_chunk ? c : last_chunk];
 	}
+	// the stage image is cleared while the loads are in flight (the barrier of phase 2 orders it before the first OR)
+	for (uint32_t i = tid; i < kEncImageWords + 4; i += kEncThreads) img[i] = 0ull;
 
 	// ---- 2. min / max under the rule.  A round whose 1024 chunks all lie inside the segment (wave-uniform test; all
 	// rounds but the first of a misplaced segment and the last one) takes a body without row or NULL tests; for the
@@ -215,6 +229,64 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 	// ---- 4. pack from the registers, stage by stage
 	const U sub = (U)(((flags & ADAC_SEG_PACKED) && stored_min != ADAC_NO_MIN) ? stored_min : 0ull); // column_segment.cpp:371-373
 	const U wmask = (U)mask64(w);
+
+	// ---- 4a. whole-dword strings go straight from the registers to the arena.  When a chunk's K fields fill a whole
+	// number of dwords (K w a multiple of 32: every byte-multiple width of the 4-byte types, 16 / 32 / 48 / 64 bits of
+	// the 8-byte ones — the padded mode's widths (column_segment.cpp:357-359) and C2's w = 32) and the rows before the
+	// segment's first one fill whole dwords too, thread t's string IS dwords [c nd - skip, c nd - skip + nd) of the
+	// segment: one coalesced store per chunk, no LDS image, no barrier, and the stores of a round overlap the next
+	// round's arithmetic.  The image path below cost ~20 vector instructions + 3 ds_or per chunk plus the copy-out.
+	if (!validity && ((K * w) & 31u) == 0u && ((align * w) & 31u) == 0u && (w <= 32u || w == type_bits)) {
+		const uint32_t nd = (K * w) >> 5;                                              // dwords per chunk: 1..4
+		const uint32_t skip = (align * w) >> 5;                                        // dwords of the rows before row 0
+		const uint32_t nd_total = 2u * (uint32_t)(((uint64_t)n * w + 63u) >> 6);       // the segment's words, in dwords
+		uint32_t *__restrict__ dst32 = reinterpret_cast<uint32_t *>(dst);
+#pragma unroll
+		for (int r = 0; r < kEncRounds; r++) {
+			const uint32_t round_row = (uint32_t)r * ROUND_ROWS;
+			if (round_row >= n + align) break; // uniform
+			const uint32_t c = (uint32_t)r * kEncThreads + tid;
+			const bool interior = round_row >= align && round_row + ROUND_ROWS - align <= n; // uniform
+			U v[K];
+			__builtin_memcpy(v, &q[r], 16);
+			if (!interior) { // rows outside the segment leave no bit
+				const int32_t row0 = (int32_t)(c * K) - (int32_t)align;
+#pragma unroll
+				for (int j = 0; j < K; j++) {
+					if ((uint32_t)(row0 + j) >= n) v[j] = sub;
+				}
+			}
+			uint32_t s[4];
+			if (w == type_bits) { // unpacked: the words are the rows
+				__builtin_memcpy(s, v, 16);
+			} else {
+				const Str128 str = chunk_string32<U>(v, (uint32_t)sub, (uint32_t)wmask, w);
+				s[0] = str.s0, s[1] = str.s1, s[2] = str.s2, s[3] = str.s3;
+			}
+			const uint32_t g0 = c * nd - skip; // wraps for the chunk that holds rows before row 0: tested per dword
+			if (interior) {
+				uint32_t *__restrict__ o = dst32 + g0;
+				if (nd == 1u) {
+					o[0] = s[0];
+				} else if (nd == 2u) {
+					store_dwords<2>(o, s);
+				} else if (nd == 3u) {
+					store_dwords<3>(o, s);
+				} else {
+					store_dwords<4>(o, s);
+				}
+			} else if (c < nchunks) {
+#pragma unroll
+				for (uint32_t j = 0; j < 4u; j++) {
+					if (j < nd && g0 + j < nd_total) dst32[g0 + j] = s[j];
+				}
+				// the upper half of the last word when the strings end one dword short of it
+				if (c == nchunks - 1u && g0 + nd < nd_total) dst32[nd_total - 1u] = 0u;
+			}
+		}
+		return;
+	}
+
 	uint32_t rps = (kEncImageWords * 64u) / (ROUND_ROWS * w); // whole rounds per stage
 	rps = rps < 1u ? 1u : rps;
 	uint32_t stage_lo = 0; // first row of the current stage (a multiple of ROUND_ROWS)
