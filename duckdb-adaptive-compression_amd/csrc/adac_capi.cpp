@@ -311,6 +311,13 @@ extern "C" uint32_t adac_tile_values(int t) {
 	return ts ? adac::tile_values(ts) : 0;
 }
 
+// diagnostic: the phase time stamps the single-pass encode recorded (8 x u64 per workgroup ticket) when the tuning knob
+// "encode_stamps" is set; not part of the drop-in boundary
+extern "C" int adac_debug_encode_stamps(void *host, uint64_t bytes) {
+	if (!host) return 1;
+	return adac::read_encode_stamps(host, bytes) == hipSuccess ? 0 : 1;
+}
+
 extern "C" int adac_set_tuning(const char *name, int value) {
 	if (!name) return 1;
 	const std::string n(name);
@@ -319,6 +326,8 @@ extern "C" int adac_set_tuning(const char *name, int value) {
 	else if (n == "sel_debug") adac::g_tuning.sel_debug = value;
 	else if (n == "grouped_repack") adac::g_tuning.grouped_repack = value;
 	else if (n == "single_pass_encode") adac::g_tuning.single_pass_encode = value;
+	else if (n == "encode_stamps") adac::g_tuning.encode_stamps = value;
+	else if (n == "encode_placement") adac::g_tuning.encode_placement = value;
 	else if (n == "templated_scan") adac::g_tuning.templated_scan = value;
 	else if (n == "scan_tiles_per_wg" && value >= 0) adac::g_tuning.scan_tiles_per_wg = value; // 0 = by type
 	else if (n == "blocks_per_cu" && value > 0) adac::g_tuning.blocks_per_cu = value;
@@ -727,7 +736,7 @@ extern "C" adac_status adac_encode(adac_layout *l, const void *d_vals, const uin
 		if (rule != ADAC_RULE_APPEND && rule != ADAC_RULE_RECOMPACT) return ADAC_ERR_INVALID_ARGUMENT;
 		if (!aligned16(d_vals) || !aligned16(d_words)) return ADAC_ERR_INVALID_ARGUMENT;
 		ADAC_HIP(hipSetDevice(l->ctx->device));
-		if (!l->d_scan_state) ADAC_HIP(hipMalloc(&l->d_scan_state, (l->nseg + 2) * sizeof(uint64_t)));
+		if (!l->d_scan_state) ADAC_HIP(hipMalloc(&l->d_scan_state, adac::encode_1p_state_words(l->nseg) * sizeof(uint64_t)));
 		ADAC_HIP(adac::launch_encode_1p(l->ctx->stream, l->type_size, l->is_signed, l->null_bits, rule,
 		                                pad_to_byte ? 1 : 0, l->d_descs, l->nseg, d_vals, d_validity, l->d_minmax,
 		                                l->d_scan_state, d_words));

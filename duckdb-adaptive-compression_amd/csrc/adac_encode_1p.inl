@@ -5,18 +5,21 @@
 // min/max + BitCompressFromSuccinct, succinct.cpp:286-299 + column_segment.cpp:365-376) read a segment twice; as two
 // kernels that is 2.0 GB of HBM traffic for the 1.2 GB C2 needs.  Here ONE workgroup of 1024 threads owns a whole
 // segment (<= 256 KiB of raw rows = sixteen 16-byte chunks per thread) and keeps it in REGISTERS across the phases:
-//   1. all sixteen loads of a thread are issued back to back (256 KiB in flight per CU).  A segment fills half of a
-//      CU's register file, so there is ONE workgroup per CU and its load phase cannot overlap another workgroup's
-//      compute phase: the kernel alternates between them, which is why it gains 9 % on the three-kernel form (0.33 vs
-//      0.36 ms at C2) and not the 40 % the byte count promises.  A persistent form that hands a packed round's
-//      registers to the next segment's loads was built and measured SLOWER (0.40 ms): the compiler spills two of the
-//      sixteen chunks under the extra pressure, and every scratch reload waits for all loads in flight;
+//   1. all sixteen loads of a thread are issued back to back.  A segment fills half of a CU's register file, so there
+//      is ONE workgroup per CU — and a CU streams at ~27 GB/s whatever the other CUs do (phase stamps,
+//      profiles/r02_encode_experiments_2.json): while a workgroup reduces, waits in the look-back and packs, its CU's
+//      memory pipe idles, which is why one segment per launch-time workgroup reads at 2.8 TB/s.  So the kernel is
+//      PERSISTENT (one workgroup per CU, segments from a ticket counter) and keeps the pipe busy through those
+//      phases: the first kEncPrefetch rounds of the NEXT segment travel global -> LDS with LDS-DMA
+//      (global_load_lds_dwordx4: no destination registers, so nothing is spilled and no wait is forced — the variant
+//      that handed registers over ran 0.40 ms) while the current one is processed, and move LDS ->
+//      registers at the top of the next iteration while its remaining rounds load;
 //   2. min / max under the rule (wave shuffles -> 16 partials through LDS), minmax[] written for adac_layout_get_minmax;
 //   3. width, flags, stored min: exactly k_plan's arithmetic; the segment's arena footprint is published and its
 //      arena offset obtained by a DECOUPLED LOOK-BACK over the predecessors' published footprints (one 64-bit word per
 //      segment: 2 flag bits + value), so the result is the same exclusive prefix k_plan's single-workgroup scan gives.
-//      Workgroups take their segment from a ticket counter, so every predecessor of a waiting workgroup is already
-//      running and publishes its footprint without depending on anybody: the wait always ends;
+//      Workgroups take their segments from a ticket counter and process their own in increasing order, so the lowest
+//      unfinished segment is always some workgroup's CURRENT one and depends on nobody: every wait ends;
 //   4. pack from the registers: a thread's K rows -> one bit string (concat_fields) -> ds_or_b64 into a zeroed LDS
 //      image of the output words of a STAGE (as many 1024-chunk rounds as fit 48 KiB), copied out with 16-byte stores.
 // Stages cover rows [r0 * 1024 K, r1 * 1024 K): multiples of 64 rows, so a stage's bits start on a word (in fact
@@ -28,6 +31,7 @@
 constexpr int kEncThreads = 1024;
 constexpr int kEncRounds = 16;                         // 16-byte chunks per thread
 constexpr uint32_t kEncImageWords = 48 * 1024 / 8;     // LDS image of one stage's output words
+constexpr int kEncPrefetch = 6;                        // rounds of the next segment prefetched into LDS (96 KiB)
 constexpr unsigned long long kScanFlagAggregate = 1ull << 62, kScanFlagPrefix = 2ull << 62, kScanValueMask = (1ull << 62) - 1;
 
 // exclusive prefix of the footprints of segments [0, seg): wave 0 of the workgroup, all 64 lanes
@@ -76,32 +80,78 @@ __device__ __forceinline__ void store_dwords(uint32_t *p, const uint32_t *s) {
 	*reinterpret_cast<Pack *>(p) = v;
 }
 
+// diagnostic time stamps (tuning knob "encode_stamps"): thread 0 records the 100 MHz wall clock at the phase boundaries
+// of every segment it processes; slot 7 holds the hardware id (XCC / SE / CU): adac_debug_encode_stamps reads them back
+constexpr uint32_t kEncStampSlots = 8, kEncStampMax = 16384;
+__device__ unsigned long long g_enc_stamps[kEncStampMax * kEncStampSlots];
+#define ADAC_STAMP(k)                                                                                                  \
+	do {                                                                                                               \
+		if (stamps && tid == 0u && seg < kEncStampMax) g_enc_stamps[seg * kEncStampSlots + (k)] = wall_clock64();      \
+	} while (0)
+
+// what a workgroup needs to know of a segment before its rows arrive (all wave-uniform)
+template <typename U>
+struct EncSegment {
+	uint32_t seg, n, align, nchunks, last_chunk;
+	uint64_t val_off;
+	const uint4 *base16; // the 16-byte chunk holding the segment's first row
+};
+
+template <typename U>
+__device__ __forceinline__ EncSegment<U> enc_segment(const adac_segment_desc *__restrict__ descs, const U *__restrict__ vals,
+                                                     uint32_t seg, uint32_t nseg) {
+	constexpr int K = 16 / (int)sizeof(U);
+	EncSegment<U> g;
+	g.seg = seg;
+	// a ticket past the end describes an empty segment that reads (and ignores) the first descriptor
+	const adac_segment_desc d = descs[seg < nseg ? seg : 0u];
+	g.n = seg < nseg ? d.count : 0u;
+	g.val_off = d.val_off;
+	g.align = (uint32_t)(d.val_off & (K - 1));
+	// 16-byte aligned; chunk c = elements [c K, c K + K).  An empty segment reads (and ignores) a descriptor: its val_off
+	// may be the end of the value buffer
+	g.base16 = g.n ? reinterpret_cast<const uint4 *>(vals + (d.val_off - g.align)) : reinterpret_cast<const uint4 *>(descs);
+	g.nchunks = (g.n + g.align + K - 1) / K; // <= 16 * 1024 (checked by the host)
+	g.last_chunk = g.nchunks ? g.nchunks - 1u : 0u;
+	return g;
+}
+
+// a barrier that orders the workgroup's LDS traffic only.  __syncthreads() also drains every vector memory operation
+// of the wave (s_waitcnt vmcnt(0)): the stores of the stage just written out, and the LDS-DMA prefetch in flight
+__device__ __forceinline__ void lds_barrier() {
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// descs_in is the same table as descs, read-only: the fields the kernel reads (count, val_off) are never written, and
+// a const __restrict__ view lets them come through the scalar cache — a vector load would queue behind the wave's
+// other vector memory operations (vmcnt returns in order)
 template <typename U>
 __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__restrict__ descs,
+                                                           const adac_segment_desc *__restrict__ descs_in, uint32_t nseg,
                                                            uint64_t *__restrict__ minmax, const U *__restrict__ vals,
                                                            const uint64_t *__restrict__ validity, int sign_extend,
                                                            uint64_t null_bits, int rule, int pad,
                                                            unsigned long long *__restrict__ scan_state,
-                                                           uint32_t *__restrict__ ticket, uint64_t *__restrict__ words) {
+                                                           uint32_t *__restrict__ ticket, uint64_t *__restrict__ words,
+                                                           int stamps, int placement) {
 	constexpr int K = 16 / (int)sizeof(U);
 	constexpr uint32_t ROUND_ROWS = kEncThreads * K; // rows one round of chunks covers: a multiple of 64
 	constexpr uint32_t type_bits = 8 * sizeof(U);
 	using S = typename std::make_signed<U>::type;
+	__shared__ __attribute__((aligned(16))) uint4 stage[kEncPrefetch * kEncThreads]; // the next segment's first rounds
 	__shared__ __attribute__((aligned(16))) unsigned long long img[kEncImageWords + 4];
 	__shared__ uint64_t pmin[kEncThreads / 64], pmax[kEncThreads / 64];
 	__shared__ uint64_t s_word_off;
-	__shared__ uint32_t s_seg;
-	const uint32_t tid = threadIdx.x;
-	if (tid == 0) s_seg = atomicAdd(ticket, 1u);
+	__shared__ uint32_t s_ticket;
+	const uint32_t tid0 = threadIdx.x;
+	uint32_t tid = tid0;
+
+	if (tid == 0) s_ticket = atomicAdd(ticket, 1u);
+	for (uint32_t i = tid; i < kEncImageWords + 4; i += kEncThreads) img[i] = 0ull;
 	__syncthreads();
-	const uint32_t seg = s_seg;
-	const adac_segment_desc d = descs[seg];
-	const uint32_t n = d.count;
-	const uint32_t align = (uint32_t)(d.val_off & (K - 1));
-	// 16-byte aligned; chunk c = elements [c K, c K + K).  An empty segment reads (and ignores) its own descriptor:
-	// its val_off may be the end of the value buffer
-	const U *__restrict__ base = n ? vals + (d.val_off - align) : reinterpret_cast<const U *>(descs + seg);
-	const uint32_t nchunks = (n + align + K - 1) / K;         // <= 16 * 1024 (checked by the host)
+	const uint32_t t0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ticket);
+	if (t0 >= nseg) return;
+	EncSegment<U> cur = enc_segment<U>(descs_in, vals, t0, nseg);
 
 	// ---- 1. the whole segment into registers.  UNCONDITIONAL loads (index clamped to the segment's last chunk): a
 	// load under a condition gets its own s_waitcnt from the compiler and the sixteen round trips would run one after
@@ -109,14 +159,54 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 	// previous segment, the ones after its last row lie inside the same aligned 16 bytes of the buffer; both are
 	// masked out below by their row numbers.
 	uint4 q[kEncRounds];
-	const uint32_t last_chunk = nchunks ? nchunks - 1u : 0u;
 #pragma unroll
 	for (int r = 0; r < kEncRounds; r++) {
 		const uint32_t c = (uint32_t)r * kEncThreads + tid;
-		q[r] = reinterpret_cast<const uint4 *>(base)[c < last_chunk ? c : last_chunk];
+		q[r] = cur.base16[c < cur.last_chunk ? c : cur.last_chunk];
 	}
-	// the stage image is cleared while the loads are in flight (the barrier of phase 2 orders it before the first OR)
-	for (uint32_t i = tid; i < kEncImageWords + 4; i += kEncThreads) img[i] = 0ull;
+
+	for (;;) {
+	// (the thread index is made opaque once per segment: everything derived from it — sixteen rounds of chunk numbers,
+	// byte offsets, LDS addresses — is loop invariant, and hoisted out of this loop it costs more registers than the
+	// segment leaves free: the compiler then keeps the sixteen chunks in scratch memory)
+	tid = tid0;
+	asm volatile("" : "+v"(tid));
+	const uint32_t wave_chunk0 = tid & ~63u; // first chunk of this wave inside a round
+	// rounds [0, kEncPrefetch) of a segment, global -> LDS, fire and forget.  Wave 0 copies nothing: its look-back
+	// loads would queue behind its own copies (a wave's vector memory operations return in order) and the whole
+	// workgroup waits for that look-back; the last wave copies wave 0's pieces as well.  The barrier of phase 3
+	// (__syncthreads: every wave drains its vmcnt first) orders the copies before the reads at the top of the next
+	// iteration
+	auto prefetch = [&](const EncSegment<U> &g) {
+		if (g.seg >= nseg || tid < 64u) return; // uniform per wave
+#pragma unroll
+		for (int r = 0; r < kEncPrefetch; r++) {
+			const uint32_t c = (uint32_t)r * kEncThreads + tid;
+			__builtin_amdgcn_global_load_lds((gptr_t)(g.base16 + (c < g.last_chunk ? c : g.last_chunk)),
+			                                 (lptr_t)(stage + (uint32_t)r * kEncThreads + wave_chunk0), 16, 0, 0);
+		}
+		if (tid >= kEncThreads - 64u) {
+#pragma unroll
+			for (int r = 0; r < kEncPrefetch; r++) {
+				const uint32_t c = (uint32_t)r * kEncThreads + (tid & 63u);
+				__builtin_amdgcn_global_load_lds((gptr_t)(g.base16 + (c < g.last_chunk ? c : g.last_chunk)),
+				                                 (lptr_t)(stage + (uint32_t)r * kEncThreads), 16, 0, 0);
+			}
+		}
+	};
+	const uint32_t seg = cur.seg;
+	const uint32_t n = cur.n, align = cur.align, nchunks = cur.nchunks;
+	const uint64_t seg_val_off = cur.val_off;
+	ADAC_STAMP(0);
+	if (stamps && tid == 0u && seg < kEncStampMax) {
+		uint32_t hw, xcc;
+		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+		g_enc_stamps[seg * kEncStampSlots + 7] = ((unsigned long long)xcc << 32) | hw;
+	}
+	// the next segment's ticket: its round trip hides behind this segment's min / max, and the barrier of phase 2
+	// publishes it
+	if (tid == 0) s_ticket = atomicAdd(ticket, 1u);
 
 	// ---- 2. min / max under the rule.  A round whose 1024 chunks all lie inside the segment (wave-uniform test; all
 	// rounds but the first of a misplaced segment and the last one) takes a body without row or NULL tests; for the
@@ -129,7 +219,7 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 #pragma unroll
 	for (int r = 0; r < kEncRounds; r++) {
 		const uint32_t round_row = (uint32_t)r * ROUND_ROWS;
-		if (round_row >= n + align) break;
+		if (round_row >= n + align) continue; // (not `break`: a constant trip count keeps the loop unrollable inside the segment loop)
 		const bool interior = !validity && round_row >= align && round_row + ROUND_ROWS - align <= n; // uniform
 		U v[K];
 		__builtin_memcpy(v, &q[r], 16);
@@ -148,7 +238,7 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 		} else {
 			const uint32_t c = (uint32_t)r * kEncThreads + tid;
 			const int32_t row0 = (int32_t)(c * K) - (int32_t)align;
-			const uint32_t vbits = chunk_validity(validity, (d.val_off - align) + (uint64_t)c * K);
+			const uint32_t vbits = chunk_validity(validity, (seg_val_off - align) + (uint64_t)c * K);
 #pragma unroll
 			for (int j = 0; j < K; j++) {
 				if (c >= nchunks || (uint32_t)(row0 + j) >= n) continue;
@@ -171,13 +261,19 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 		mn = a < mn ? a : mn;
 		mx = b > mx ? b : mx;
 	}
+	ADAC_STAMP(1);
 	mn = wave_min(mn);
 	mx = wave_max(mx);
 	if ((tid & 63u) == 0u) {
 		pmin[tid >> 6] = mn;
 		pmax[tid >> 6] = mx;
 	}
-	__syncthreads();
+	lds_barrier();
+	// this segment's rows are all in registers: from here to the end of the pack the CU's memory pipe would idle, so
+	// the first rounds of the next segment start travelling now
+	const EncSegment<U> nxt = enc_segment<U>(descs_in, vals, (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ticket), nseg);
+	prefetch(nxt);
+	ADAC_STAMP(2);
 #pragma unroll
 	for (int i = 0; i < kEncThreads / 64; i++) {
 		mn = pmin[i] < mn ? pmin[i] : mn;
@@ -201,30 +297,51 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 		}
 	}
 	const uint64_t footprint = ((((uint64_t)n * w + 64) >> 6) + 15) & ~15ull; // SDSL allocation, rounded to 128 B
-	if (tid < 64) {
-		if (tid == 0) { // publish the own footprint first: successors can then pass over this segment
-			__hip_atomic_store(&scan_state[seg], (seg == 0 ? kScanFlagPrefix : kScanFlagAggregate) | footprint,
-			                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		}
-		const uint64_t excl = seg == 0 ? 0ull : lookback_exclusive(scan_state, seg);
-		if (tid == 0) {
-			if (seg != 0) {
-				__hip_atomic_store(&scan_state[seg], kScanFlagPrefix | (excl + footprint), __ATOMIC_RELAXED,
-				                   __HIP_MEMORY_SCOPE_AGENT);
-			}
-			s_word_off = excl;
-			minmax[2 * (uint64_t)seg] = mn;
-			minmax[2 * (uint64_t)seg + 1] = mx;
-			descs[seg].word_off = excl;
-			descs[seg].min = stored_min;
-			descs[seg].width = (uint8_t)w;
-			descs[seg].flags = flags;
-			descs[seg].reserved = 0;
-		}
+	if (tid == 0) { // publish the own footprint first: successors can then pass over this segment
+		__hip_atomic_store(&scan_state[seg], (seg == 0 ? kScanFlagPrefix : kScanFlagAggregate) | footprint,
+		                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
-	__syncthreads();
-	if (n == 0) return;
-	unsigned long long *__restrict__ dst = reinterpret_cast<unsigned long long *>(words) + uniform64(s_word_off);
+	// The arena offset is only needed by the first STORE, and it is obtained as late as that.  The look-back waits for
+	// the slowest of the predecessors in flight (256 workgroups with two segments each: an extreme-value wait of
+	// 5 - 11 us per segment when it followed the publication at once, profiles/r02_encode_experiments_2.json); every
+	// piece of work that fits between publishing the footprint and asking for the prefix shortens it.
+	unsigned long long *__restrict__ dst = nullptr;
+	const int first_come = placement; // 1: arena order = order of completion (no wait at all; offsets differ run to run)
+	auto place = [&]() {
+		if (tid < 64) {
+			uint64_t excl;
+			if (first_come) {
+				unsigned long long got = 0;
+				if (tid == 0) got = atomicAdd(scan_state + nseg + 1, (unsigned long long)footprint);
+				excl = uniform64(got);
+			} else {
+				excl = seg == 0 ? 0ull : lookback_exclusive(scan_state, seg);
+			}
+			if (tid == 0) {
+				if (seg != 0 && !first_come) {
+					__hip_atomic_store(&scan_state[seg], kScanFlagPrefix | (excl + footprint), __ATOMIC_RELAXED,
+					                   __HIP_MEMORY_SCOPE_AGENT);
+				}
+				s_word_off = excl;
+				minmax[2 * (uint64_t)seg] = mn;
+				minmax[2 * (uint64_t)seg + 1] = mx;
+				descs[seg].word_off = excl;
+				descs[seg].min = stored_min;
+				descs[seg].width = (uint8_t)w;
+				descs[seg].flags = flags;
+				descs[seg].reserved = 0;
+			}
+			ADAC_STAMP(5); // (diagnostic: the look-back itself, before the barrier that also waits for the prefetch)
+		}
+		__syncthreads(); // also drains every wave's vmcnt: the LDS-DMA prefetch has landed when the pack is over
+		ADAC_STAMP(3);
+		dst = reinterpret_cast<unsigned long long *>(words) + uniform64(s_word_off);
+	};
+	do { // phase 4 (left with `break` where the one-segment form returned)
+	if (n == 0) {
+		place();
+		break;
+	}
 
 	// ---- 4. pack from the registers, stage by stage
 	const U sub = (U)(((flags & ADAC_SEG_PACKED) && stored_min != ADAC_NO_MIN) ? stored_min : 0ull); // column_segment.cpp:371-373
@@ -240,11 +357,11 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 		const uint32_t nd = (K * w) >> 5;                                              // dwords per chunk: 1..4
 		const uint32_t skip = (align * w) >> 5;                                        // dwords of the rows before row 0
 		const uint32_t nd_total = 2u * (uint32_t)(((uint64_t)n * w + 63u) >> 6);       // the segment's words, in dwords
-		uint32_t *__restrict__ dst32 = reinterpret_cast<uint32_t *>(dst);
+		// the strings replace the rows in the registers (the look-back has the time this takes) ...
 #pragma unroll
 		for (int r = 0; r < kEncRounds; r++) {
 			const uint32_t round_row = (uint32_t)r * ROUND_ROWS;
-			if (round_row >= n + align) break; // uniform
+			if (round_row >= n + align) continue; // uniform
 			const uint32_t c = (uint32_t)r * kEncThreads + tid;
 			const bool interior = round_row >= align && round_row + ROUND_ROWS - align <= n; // uniform
 			U v[K];
@@ -256,13 +373,24 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 					if ((uint32_t)(row0 + j) >= n) v[j] = sub;
 				}
 			}
-			uint32_t s[4];
-			if (w == type_bits) { // unpacked: the words are the rows
-				__builtin_memcpy(s, v, 16);
-			} else {
+			if (w != type_bits) { // (unpacked: the words are the rows)
 				const Str128 str = chunk_string32<U>(v, (uint32_t)sub, (uint32_t)wmask, w);
-				s[0] = str.s0, s[1] = str.s1, s[2] = str.s2, s[3] = str.s3;
+				q[r] = make_uint4(str.s0, str.s1, str.s2, str.s3);
+			} else if (!interior) {
+				__builtin_memcpy(&q[r], v, 16);
 			}
+		}
+		place();
+		// ... and leave for the arena
+		uint32_t *__restrict__ dst32 = reinterpret_cast<uint32_t *>(dst);
+#pragma unroll
+		for (int r = 0; r < kEncRounds; r++) {
+			const uint32_t round_row = (uint32_t)r * ROUND_ROWS;
+			if (round_row >= n + align) continue; // uniform
+			const uint32_t c = (uint32_t)r * kEncThreads + tid;
+			const bool interior = round_row >= align && round_row + ROUND_ROWS - align <= n; // uniform
+			uint32_t s[4];
+			__builtin_memcpy(s, &q[r], 16);
 			const uint32_t g0 = c * nd - skip; // wraps for the chunk that holds rows before row 0: tested per dword
 			if (interior) {
 				uint32_t *__restrict__ o = dst32 + g0;
@@ -284,7 +412,7 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 				if (c == nchunks - 1u && g0 + nd < nd_total) dst32[nd_total - 1u] = 0u;
 			}
 		}
-		return;
+		break;
 	}
 
 	uint32_t rps = (kEncImageWords * 64u) / (ROUND_ROWS * w); // whole rounds per stage
@@ -297,7 +425,7 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 		U v[K];
 		__builtin_memcpy(v, &chunk, 16);
 		if (validity) {
-			const uint32_t vbits = chunk_validity(validity, (d.val_off - align) + (uint64_t)c * K);
+			const uint32_t vbits = chunk_validity(validity, (seg_val_off - align) + (uint64_t)c * K);
 #pragma unroll
 			for (int j = 0; j < K; j++) v[j] = ((vbits >> j) & 1u) ? v[j] : (U)null_bits; // NullValue<T> (succinct.cpp:288-291)
 		}
@@ -336,7 +464,8 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 	};
 	// the image holds rows [stage_lo, hi): out to the arena, and zero again
 	auto flush = [&](uint32_t hi) {
-		__syncthreads();
+		if (!dst) place(); // uniform: the first stage is in the image, now the arena offset is needed
+		lds_barrier();
 		const uint32_t nwords = ((hi - stage_lo) * w + 63u) >> 6;
 		unsigned long long *__restrict__ out = dst + (((uint64_t)stage_lo * w) >> 6);
 		for (uint32_t i = 2u * tid; i < nwords; i += 2u * kEncThreads) {
@@ -354,14 +483,14 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 				out[i] = v0;
 			}
 		}
-		__syncthreads();
+		lds_barrier();
 	};
 	const uint32_t p_thread = (tid * K - align) * w; // bit position of this thread's chunk inside round 0 (wraps for
 	                                                  // thread 0 of a misplaced segment: that chunk goes row by row)
 #pragma unroll
 	for (int r = 0; r < kEncRounds; r++) {
 		const uint32_t round_row = (uint32_t)r * ROUND_ROWS;
-		if (round_row >= n + align) break; // uniform: no chunk of this or a later round holds a row
+		if (round_row >= n + align) continue; // uniform: no chunk of this or a later round holds a row
 		const uint32_t c = (uint32_t)r * kEncThreads + tid;
 		if (r > 0 && ((uint32_t)r % rps) == 0u && round_row < n) { // uniform: a stage ends before this round
 			// thread 0's chunk of this round starts `align` rows before the boundary: those rows belong to the stage
@@ -385,4 +514,20 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 		}
 	}
 	flush(n);
+	} while (0);
+	ADAC_STAMP(4);
+
+	// ---- the next segment: its first rounds are in LDS (or on their way), the rest is loaded now, and the segment
+	// after it is prefetched behind those loads
+	if (nxt.seg >= nseg) break; // uniform: the column is done
+	cur = nxt;
+#pragma unroll
+	for (int r = 0; r < kEncPrefetch; r++) q[r] = stage[(uint32_t)r * kEncThreads + tid];
+	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the staged chunks are in registers before LDS-DMA may overwrite them
+#pragma unroll
+	for (int r = kEncPrefetch; r < kEncRounds; r++) {
+		const uint32_t c = (uint32_t)r * kEncThreads + tid;
+		q[r] = cur.base16[c < cur.last_chunk ? c : cur.last_chunk];
+	}
+	}
 }

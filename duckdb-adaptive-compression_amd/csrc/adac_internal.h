@@ -71,6 +71,8 @@ hipError_t launch_unpack_jobs(hipStream_t s, uint32_t type_size, const UnpackJob
 struct Tuning {
 	int persistent_unpack = 0;  // measured 5-15 % slower than one tile per workgroup (profiles/r01_ab_*.json)
 	int single_pass_encode = 1; // A/B: 0 = analyze + plan + pack as three kernels (the raw column is read twice)
+	int encode_placement = 0;   // single-pass encode: 0 = arena order is segment order (look-back), 1 = order of completion
+	int encode_stamps = 0;      // diagnostic: phase time stamps of the single-pass encode (adac_debug_encode_stamps)
 	int grouped_repack = 1;     // A/B: 0 = one tile per workgroup with the 16 KiB row image (the first version)
 	int sel_debug = 0;          // diagnostic: selection scan without its flush (1) / without any bitmap emit (2)
 	int scan_probe = 0;         // diagnostic: fused-scan loop + loads only (no field walk)
@@ -110,6 +112,9 @@ hipError_t launch_repack(hipStream_t s, uint32_t type_size, uint64_t null_bits, 
 // single-pass encode (adac_encode_1p.inl): every segment must fit sixteen 16-byte chunks per thread of a 1024-thread
 // workgroup, counted from the 16-byte boundary at or before its first element
 constexpr uint64_t kEncodeOnePassBytes = 16ull * 1024 * 16;
+// 64-bit words of device scratch the single-pass encode needs for nseg segments (look-back words, ticket)
+inline uint64_t encode_1p_state_words(uint64_t nseg) { return nseg + 2; }
+hipError_t read_encode_stamps(void *host, uint64_t bytes);
 hipError_t launch_encode_1p(hipStream_t s, uint32_t type_size, bool sign_extend, uint64_t null_bits, int rule,
                             int pad_to_byte, adac_segment_desc *d_descs, uint64_t nseg, const void *d_vals,
                             const uint64_t *d_validity, uint64_t *d_minmax, void *d_scan_state, uint64_t *d_words);

@@ -1854,16 +1854,24 @@ hipError_t launch_encode_1p(hipStream_t s, uint32_t type_size, bool sign_extend,
                             const uint64_t *d_validity, uint64_t *d_minmax, void *d_scan_state, uint64_t *d_words) {
 	if (nseg == 0) return hipSuccess;
 	// scan_state: nseg look-back words followed by the ticket counter, all zero before the launch
-	hipError_t e = hipMemsetAsync(d_scan_state, 0, (nseg + 1) * sizeof(unsigned long long), s);
+	hipError_t e = hipMemsetAsync(d_scan_state, 0, (nseg + 2) * sizeof(unsigned long long), s);
 	if (e != hipSuccess) return e;
+	// persistent: one workgroup per CU (a segment fills half a CU's register file), segments handed out by ticket
+	const uint64_t cus = g_tuning.num_cus > 0 ? (uint64_t)g_tuning.num_cus : 256;
+	const unsigned grid = (unsigned)(nseg < cus ? nseg : cus);
 	return dispatch_size(type_size, [&](auto tag) {
 		using U = decltype(tag);
 		unsigned long long *state = static_cast<unsigned long long *>(d_scan_state);
-		hipLaunchKernelGGL(k_encode_1p<U>, dim3((unsigned)nseg), dim3(kEncThreads), 0, s, d_descs, d_minmax,
+		hipLaunchKernelGGL(k_encode_1p<U>, dim3(grid), dim3(kEncThreads), 0, s, d_descs, d_descs, (uint32_t)nseg, d_minmax,
 		                   static_cast<const U *>(d_vals), d_validity, sign_extend ? 1 : 0, null_bits, rule, pad_to_byte,
-		                   state, reinterpret_cast<uint32_t *>(state + nseg), d_words);
+		                   state, reinterpret_cast<uint32_t *>(state + nseg), d_words, g_tuning.encode_stamps, g_tuning.encode_placement);
 		return hipGetLastError();
 	});
+}
+
+hipError_t read_encode_stamps(void *host, uint64_t bytes) {
+	const uint64_t cap = sizeof(unsigned long long) * kEncStampMax * kEncStampSlots;
+	return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_enc_stamps), bytes < cap ? bytes : cap);
 }
 
 hipError_t launch_analyze_packed_g(hipStream_t s, uint32_t type_size, bool sign_extend, uint64_t null_bits, int rule,
