@@ -138,8 +138,16 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 	constexpr uint32_t ROUND_ROWS = kEncThreads * K; // rows one round of chunks covers: a multiple of 64
 	constexpr uint32_t type_bits = 8 * sizeof(U);
 	using S = typename std::make_signed<U>::type;
-	__shared__ __attribute__((aligned(16))) uint4 stage[kEncPrefetch * kEncThreads]; // the next segment's first rounds
-	__shared__ __attribute__((aligned(16))) unsigned long long img[kEncImageWords + 4];
+	// one LDS pool: [stage: the next segment's first rounds | img: the stage image of the pack]; the PARKING area of
+	// the whole-dword path (2 dwords x 16 rounds x 1024 threads = 128 KiB) lies over both
+	constexpr uint32_t kStageBytes = kEncPrefetch * kEncThreads * 16u, kImgBytes = (kEncImageWords + 4) * 8u;
+	static_assert(kStageBytes + kImgBytes >= 2u * 4u * kEncRounds * kEncThreads, "parking area does not fit the pool");
+	__shared__ __attribute__((aligned(16))) unsigned char pool[kStageBytes + kImgBytes];
+	uint4 *const stage = reinterpret_cast<uint4 *>(pool);
+	unsigned long long *const img = reinterpret_cast<unsigned long long *>(pool + kStageBytes);
+	uint32_t *const park = reinterpret_cast<uint32_t *>(pool);
+	bool img_dirty = false;   // the parking area was used since the image was last all zero (uniform)
+	bool next_loaded = false; // the next segment's loads were issued by the parked flow (uniform)
 	__shared__ uint64_t pmin[kEncThreads / 64], pmax[kEncThreads / 64];
 	__shared__ uint64_t s_word_off;
 	__shared__ uint32_t s_ticket;
@@ -164,6 +172,10 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 		const uint32_t c = (uint32_t)r * kEncThreads + tid;
 		q[r] = cur.base16[c < cur.last_chunk ? c : cur.last_chunk];
 	}
+	// thread 0 keeps the ticket of the segment after the current one; it is always taken BEFORE the wave's next batch
+	// of loads is issued (a wave's vector memory operations return in order: behind the loads it would arrive last)
+	uint32_t next_ticket = 0;
+	if (tid == 0) next_ticket = atomicAdd(ticket, 1u);
 
 	for (;;) {
 	// (the thread index is made opaque once per segment: everything derived from it — sixteen rounds of chunk numbers,
@@ -204,9 +216,8 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
 		g_enc_stamps[seg * kEncStampSlots + 7] = ((unsigned long long)xcc << 32) | hw;
 	}
-	// the next segment's ticket: its round trip hides behind this segment's min / max, and the barrier of phase 2
-	// publishes it
-	if (tid == 0) s_ticket = atomicAdd(ticket, 1u);
+	// the next segment's ticket (taken a batch of loads ago); the barrier of phase 2 publishes it
+	if (tid == 0) s_ticket = next_ticket;
 
 	// ---- 2. min / max under the rule.  A round whose 1024 chunks all lie inside the segment (wave-uniform test; all
 	// rounds but the first of a misplaced segment and the last one) takes a body without row or NULL tests; for the
@@ -272,7 +283,6 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 	// this segment's rows are all in registers: from here to the end of the pack the CU's memory pipe would idle, so
 	// the first rounds of the next segment start travelling now
 	const EncSegment<U> nxt = enc_segment<U>(descs_in, vals, (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ticket), nseg);
-	prefetch(nxt);
 	ADAC_STAMP(2);
 #pragma unroll
 	for (int i = 0; i < kEncThreads / 64; i++) {
@@ -307,7 +317,7 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 	// piece of work that fits between publishing the footprint and asking for the prefix shortens it.
 	unsigned long long *__restrict__ dst = nullptr;
 	const int first_come = placement; // 1: arena order = order of completion (no wait at all; offsets differ run to run)
-	auto place = [&]() {
+	auto place = [&](bool drain) {
 		if (tid < 64) {
 			uint64_t excl;
 			if (first_come) {
@@ -333,13 +343,24 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 			}
 			ADAC_STAMP(5); // (diagnostic: the look-back itself, before the barrier that also waits for the prefetch)
 		}
-		__syncthreads(); // also drains every wave's vmcnt: the LDS-DMA prefetch has landed when the pack is over
+		if (drain) {
+			__syncthreads(); // also drains every wave's vmcnt: the LDS-DMA prefetch has landed when the pack is over
+		} else {
+			lds_barrier(); // (the parked flow has the next segment's loads in flight: they must not be waited for)
+		}
 		ADAC_STAMP(3);
 		dst = reinterpret_cast<unsigned long long *>(words) + uniform64(s_word_off);
 	};
 	do { // phase 4 (left with `break` where the one-segment form returned)
+	// whole-dword strings (4a below)?  With at most two dwords per chunk the strings are PARKED in LDS, the next
+	// segment's loads are issued into the freed registers, and only then is the arena offset asked for: the look-back
+	// wait overlaps those loads instead of idling the CU's memory pipe.  Other segments prefetch through LDS-DMA.
+	const bool whole_dwords = n != 0u && !validity && ((K * w) & 31u) == 0u && ((align * w) & 31u) == 0u &&
+	                          (w <= 32u || w == type_bits);
+	const bool parked = whole_dwords && K * w <= 64u;
+	if (!parked) prefetch(nxt);
 	if (n == 0) {
-		place();
+		place(true);
 		break;
 	}
 
@@ -353,7 +374,7 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 	// segment's first one fill whole dwords too, thread t's string IS dwords [c nd - skip, c nd - skip + nd) of the
 	// segment: one coalesced store per chunk, no LDS image, no barrier, and the stores of a round overlap the next
 	// round's arithmetic.  The image path below cost ~20 vector instructions + 3 ds_or per chunk plus the copy-out.
-	if (!validity && ((K * w) & 31u) == 0u && ((align * w) & 31u) == 0u && (w <= 32u || w == type_bits)) {
+ 	if (whole_dwords) {
 		const uint32_t nd = (K * w) >> 5;                                              // dwords per chunk: 1..4
 		const uint32_t skip = (align * w) >> 5;                                        // dwords of the rows before row 0
 		const uint32_t nd_total = 2u * (uint32_t)(((uint64_t)n * w + 63u) >> 6);       // the segment's words, in dwords
@@ -380,7 +401,71 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 				__builtin_memcpy(&q[r], v, 16);
 			}
 		}
-		place();
+		if (parked) {
+			// ... are parked in LDS (every thread in slots of its own: no barrier) ...
+#pragma unroll
+			for (int r = 0; r < kEncRounds; r++) {
+				const uint32_t round_row = (uint32_t)r * ROUND_ROWS;
+				if (round_row >= n + align) continue; // uniform
+				uint32_t *slot = park + ((uint32_t)r * kEncThreads + tid) * 2u;
+				if (nd == 2u) {
+					*reinterpret_cast<uint2 *>(slot) = make_uint2(q[r].x, q[r].y);
+				} else {
+					slot[0] = q[r].x;
+				}
+			}
+			img_dirty = true;
+			// ... the next segment's rows start travelling into the freed registers (wave 0 later: its look-back loads
+			// would queue behind them) ...
+			auto load_next = [&]() {
+#pragma unroll
+				for (int r = 0; r < kEncRounds; r++) {
+					const uint32_t c = (uint32_t)r * kEncThreads + tid;
+					q[r] = nxt.base16[c < nxt.last_chunk ? c : nxt.last_chunk];
+				}
+			};
+			const bool more = nxt.seg < nseg; // uniform
+			if (more && tid >= 64u) load_next();
+			place(false);
+			// ... and the strings leave for the arena
+			uint32_t *__restrict__ out32 = reinterpret_cast<uint32_t *>(dst);
+#pragma unroll
+			for (int r = 0; r < kEncRounds; r++) {
+				const uint32_t round_row = (uint32_t)r * ROUND_ROWS;
+				if (round_row >= n + align) continue; // uniform
+				const uint32_t c = (uint32_t)r * kEncThreads + tid;
+				const bool interior = round_row >= align && round_row + ROUND_ROWS - align <= n; // uniform
+				const uint32_t *slot = park + ((uint32_t)r * kEncThreads + tid) * 2u;
+				uint32_t s[2];
+				if (nd == 2u) {
+					const uint2 t2 = *reinterpret_cast<const uint2 *>(slot);
+					s[0] = t2.x, s[1] = t2.y;
+				} else {
+					s[0] = slot[0], s[1] = 0u;
+				}
+				const uint32_t g0 = c * nd - skip;
+				if (interior) {
+					if (nd == 1u) {
+						out32[g0] = s[0];
+					} else {
+						store_dwords<2>(out32 + g0, s);
+					}
+				} else if (c < nchunks) {
+#pragma unroll
+					for (uint32_t j = 0; j < 2u; j++) {
+						if (j < nd && g0 + j < nd_total) out32[g0 + j] = s[j];
+					}
+					if (c == nchunks - 1u && g0 + nd < nd_total) out32[nd_total - 1u] = 0u;
+				}
+			}
+			if (more && tid < 64u) {
+				if (tid == 0) next_ticket = atomicAdd(ticket, 1u);
+				load_next();
+			}
+			next_loaded = more;
+			break;
+		}
+		place(true);
 		// ... and leave for the arena
 		uint32_t *__restrict__ dst32 = reinterpret_cast<uint32_t *>(dst);
 #pragma unroll
@@ -415,6 +500,12 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 		break;
 	}
 
+	if (img_dirty) { // uniform: a parked segment wrote over the image since it was last cleared
+		lds_barrier();
+		for (uint32_t i = tid; i < kEncImageWords + 4; i += kEncThreads) img[i] = 0ull;
+		lds_barrier();
+		img_dirty = false;
+	}
 	uint32_t rps = (kEncImageWords * 64u) / (ROUND_ROWS * w); // whole rounds per stage
 	rps = rps < 1u ? 1u : rps;
 	uint32_t stage_lo = 0; // first row of the current stage (a multiple of ROUND_ROWS)
@@ -464,7 +555,7 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 	};
 	// the image holds rows [stage_lo, hi): out to the arena, and zero again
 	auto flush = [&](uint32_t hi) {
-		if (!dst) place(); // uniform: the first stage is in the image, now the arena offset is needed
+		if (!dst) place(true); // uniform: the first stage is in the image, now the arena offset is needed
 		lds_barrier();
 		const uint32_t nwords = ((hi - stage_lo) * w + 63u) >> 6;
 		unsigned long long *__restrict__ out = dst + (((uint64_t)stage_lo * w) >> 6);
@@ -521,6 +612,11 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 	// after it is prefetched behind those loads
 	if (nxt.seg >= nseg) break; // uniform: the column is done
 	cur = nxt;
+	if (next_loaded) { // uniform: the parked flow already issued this segment's loads
+		next_loaded = false;
+		continue;
+	}
+	if (tid == 0) next_ticket = atomicAdd(ticket, 1u);
 #pragma unroll
 	for (int r = 0; r < kEncPrefetch; r++) q[r] = stage[(uint32_t)r * kEncThreads + tid];
 	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the staged chunks are in registers before LDS-DMA may overwrite them

@@ -646,3 +646,72 @@ def test_unpack_jobs_layout_free_batches(adac, oracle, gpu_ctx):
             bad = jobs[:1].copy()
             bad[0]["word_off"] += 1
             adac.unpack_jobs(gpu_ctx, dtype, bad, d_words, base)
+
+
+@pytest.mark.parametrize("dtype", [np.uint64, np.int64, np.uint32, np.int32])
+def test_single_pass_encode_mixes_its_flows(adac, oracle, gpu_ctx, dtype):
+    """The single-pass encode is persistent: one workgroup works through many segments and chooses per segment between
+    the parked whole-dword flow (LDS parking area over the prefetch stage and the image), the staged image flow, the
+    wide whole-dword flow and the unpacked copy.  Many more segments than CUs, of every size up to a full block, at
+    random placements, with widths that alternate between the flows: the hand-over of the LDS pool (a parked segment
+    dirties the image), of the prefetched rounds and of the early loads must never leak from one segment into the
+    next.  Compared word for word with the oracle, both rules, padded on and off, and with the three-kernel form."""
+    dtype = np.dtype(dtype)
+    tb = 8 * dtype.itemsize
+    rng = np.random.default_rng(1234 + tb + (dtype.kind == "i"))
+    full = 262136 // dtype.itemsize
+    flow_widths = [tb // 2, 13, tb, tb // 4, 3 * tb // 4, 1, tb // 2 - 1, 7, tb // 2, 24 if tb == 32 else 48]
+    nseg = 700
+    sizes = rng.choice([0, 1, 2, 3, 63, 64, 65, 1000, 2047, 2048, 4097, 16386, 22531, full - 1, full], size=nseg,
+                       p=[.03, .03, .03, .03, .04, .04, .04, .1, .1, .1, .1, .1, .1, .08, .08])
+    counts = sizes.astype(np.uint32)
+    gaps = rng.integers(0, 5, size=nseg)
+    offs, run = [], 0
+    for c, g in zip(counts, gaps):
+        run += int(g)
+        offs.append(run)
+        run += int(c)
+    seg_vals = [make_values(rng, dtype, int(c), flow_widths[int(rng.integers(0, len(flow_widths)))]) for c in counts]
+    val_offs = np.array(offs, dtype=np.uint64)
+    for rule in (adac.RULE_APPEND, adac.RULE_RECOMPACT):
+        for padded in (False, True):
+            run_encode_decode(adac, oracle, gpu_ctx, dtype, counts, seg_vals, rule, padded, val_offs=val_offs)
+    # the three-kernel form on the same column: identical descriptors and arena
+    lay1, w1, _, d1, _ = run_encode_decode(adac, oracle, gpu_ctx, dtype, counts, seg_vals, val_offs=val_offs)
+    adac.set_tuning("single_pass_encode", 0)
+    try:
+        lay3, w3, _, d3, _ = run_encode_decode(adac, oracle, gpu_ctx, dtype, counts, seg_vals, val_offs=val_offs)
+    finally:
+        adac.set_tuning("single_pass_encode", 1)
+    assert d1.tobytes() == d3.tobytes()
+    # first-come placement: same widths / mins / words per segment at offsets of its own choosing
+    adac.set_tuning("encode_placement", 1)
+    try:
+        layf = adac.Layout(gpu_ctx, dtype, counts, val_offs)
+        host_vals = np.zeros(max(layf.value_span, 1), dtype=dtype)
+        for v, o in zip(seg_vals, offs):
+            host_vals[o:o + len(v)] = v
+        d_vals = gpu_ctx.upload(host_vals)
+        d_words = gpu_ctx.alloc(layf.max_arena_words * 8 + 16).zero()
+        layf.encode(d_vals, d_words)
+        df = layf.get_descs()
+    finally:
+        adac.set_tuning("encode_placement", 0)
+    for f in ("count", "width", "flags", "min", "val_off"):
+        assert np.array_equal(df[f], d1[f]), f
+    wf = d_words.download(np.uint64, layf.max_arena_words)
+    w_ord = w1.download(np.uint64, lay1.max_arena_words)
+    foot = ((df["count"].astype(np.uint64) * df["width"] + 64) >> np.uint64(6)) + np.uint64(15) & ~np.uint64(15)
+    order = np.argsort(df["word_off"], kind="stable")
+    ends = df["word_off"][order] + foot[order]
+    assert np.all(df["word_off"] % 16 == 0) and np.all(ends[:-1] <= df["word_off"][order][1:])   # disjoint
+    assert int(ends.max()) <= layf.max_arena_words
+    for s in range(nseg):
+        nw = int((int(df["count"][s]) * int(df["width"][s]) + 63) // 64)
+        a, b = int(df["word_off"][s]), int(d1["word_off"][s])
+        assert np.array_equal(wf[a:a + nw], w_ord[b:b + nw]), "words of segment %d" % s
+    d_out = gpu_ctx.alloc(layf.value_span * dtype.itemsize + 64)
+    layf.unpack(d_words, d_out)
+    got = d_out.download(dtype, layf.value_span)
+    for v, o in zip(seg_vals, offs):
+        assert np.array_equal(got[o:o + len(v)], v)
