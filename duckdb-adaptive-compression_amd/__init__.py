@@ -102,6 +102,7 @@ SIGNATURES = {
     "adac_blocks_read": (_int, [_vp, _int, _vp, _vp, _u64, _vp, _vp]),
     "adac_tile_values": (_u32, [_int]),
     "adac_set_tuning": (_int, [C.c_char_p, _int]),
+    "adac_debug_encode_stamps": (_int, [_vp, _u64]),
     "adac_device_count": (_int, []),
     "adac_ctx_create": (_int, [_int, _vp, _P(_vp)]),
     "adac_ctx_destroy": (None, [_vp]),

@@ -140,8 +140,16 @@ uint64_t adac_block_stride(uint64_t count, uint8_t width);
 uint32_t adac_tile_values(int physical_type);
 /* Launch-shape knobs for in-process A/B measurement: "persistent_unpack", "templated_scan", "scan_probe" (0/1),
  * "scan_tiles_per_wg" (tiles per fused-scan workgroup; 0 = chosen by type), "blocks_per_cu",
- * "num_cus".  Results never depend on them.  Returns 0 if the name is known. */
+ * "num_cus", "single_pass_encode" (0 = analyze + plan + pack as three kernels).  Decoded values, packed words, widths
+ * and mins never depend on them.  One knob changes WHERE adac_encode puts a segment in the arena: "encode_placement" 1
+ * hands out arena space in order of completion (a cursor, no ordered look-back) instead of the exclusive prefix in
+ * segment order that adac_plan computes: descriptors then carry offsets that differ from run to run (disjoint,
+ * 128-byte aligned, inside max_arena_words).  "encode_stamps" 1 records diagnostic time stamps.  Returns 0 if the name
+ * is known. */
 int adac_set_tuning(const char *name, int value);
+/* Diagnostic, not part of the drop-in boundary: the phase time stamps (8 x uint64 per segment) the single-pass encode
+ * recorded while "encode_stamps" was set (tools/encode_stamps.py).  Returns 0 on success. */
+int adac_debug_encode_stamps(void *host, uint64_t bytes);
 
 /* ---------------------------------------------------------------------------------------------
  * Context and device memory.
