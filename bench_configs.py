@@ -289,6 +289,74 @@ def q6_packed(adac, n=59_986_052):
     return out
 
 
+def q1_packed(adac, n=59_986_052):
+    """C3's Q1 shape on packed columns ("Q1 = group-by sum"; benchmark log TPCH_runtime.txt:2-6):
+    SUM(l_quantity), SUM(l_extendedprice), SUM(l_partkey), COUNT(*) GROUP BY (l_returnflag, l_linestatus) on int32
+    columns of TPC-H SF10 size that share their segment layout; the group code is a 6-valued uint8 column (the
+    engine's dictionary code of the two flags).  One adac_scan_group_sum per aggregated column, nothing decoded to
+    HBM; checked against numpy's GROUP BY.  Beside it: decoding the same columns (what the reference's engine needs
+    before its hash aggregate can start)."""
+    ctx = adac.Context(0)
+    rng = np.random.default_rng(1992)
+    code = rng.choice(6, size=n, p=[.2466, .2534, .0004, .2500, .2490, .0006]).astype(np.uint8)
+    cols = {"l_quantity": rng.integers(1, 51, size=n).astype(np.int32),
+            "l_extendedprice": rng.integers(90_000, 10_495_000, size=n).astype(np.int32),
+            "l_partkey": rng.integers(1, 2_000_001, size=n).astype(np.int32)}
+    counts = adac.appender_segment_counts(n, 4)
+
+    def enc_col(v):
+        lay = adac.Layout(ctx, v.dtype, counts)
+        d_vals = ctx.upload(v)
+        d_words = ctx.alloc(lay.max_arena_words * 8 + 16).zero()
+        lay.encode(d_vals, d_words)
+        ctx.sync()
+        descs = lay.get_descs()
+        nbytes = int(((descs["count"].astype(np.uint64) * descs["width"] + 63) // 64 * 8).sum())
+        return lay, d_words, nbytes, sorted(set(descs["width"].tolist()))
+
+    klay, kwords, kbytes, kwidths = enc_col(code)
+    d_sums = ctx.alloc(7 * 8)
+    d_cnts = ctx.alloc(7 * 8)
+    out = {"rows": n, "groups": 6, "key_widths": kwidths, "key_packed_bytes": kbytes, "columns": []}
+    total_ms, total_bytes = 0.0, 0
+    reps = 20
+    for name, v in cols.items():
+        lay, words, nbytes, widths = enc_col(v)
+        lay.scan_group_sum(words, klay, kwords, 6, d_sums, d_cnts)
+        ctx.sync()
+        got_s = d_sums.download(np.uint64, 7).tolist()
+        got_c = d_cnts.download(np.uint64, 7).tolist()
+        for g in range(6):
+            m = code == g
+            assert got_c[g] == int(m.sum()) and got_s[g] == int(v[m].astype(np.int64).sum()), "Q1 parity"
+        assert got_c[6] == 0
+        ctx.timer_start()
+        for _ in range(reps):
+            lay.scan_group_sum(words, klay, kwords, 6, d_sums, d_cnts)
+        ms = ctx.timer_stop() / reps
+        d_out = ctx.alloc(n * 4 + 64)
+        lay.unpack(words, d_out)
+        ctx.timer_start()
+        for _ in range(reps):
+            lay.unpack(words, d_out)
+        ms_dec = ctx.timer_stop() / reps
+        del d_out
+        total_ms += ms
+        total_bytes += nbytes + kbytes
+        out["columns"].append({"column": name, "widths": widths, "packed_bytes": nbytes, "group_sum_ms": ms,
+                               "rows_per_s": n / (ms * 1e-3), "packed_read_GBps": (nbytes + kbytes) / (ms * 1e-3) / 1e9,
+                               "decode_only_ms": ms_dec})
+        del lay, words
+    out["q1_three_aggregates_ms"] = total_ms
+    out["q1_rows_per_s"] = n / (total_ms * 1e-3)
+    out["q1_packed_read_GBps"] = total_bytes / (total_ms * 1e-3) / 1e9
+    out["note"] = ("one grouped scan per aggregated column over (value, group code); per-thread LDS bins (7 bins), one "
+                   "partial per workgroup, k_group_final adds them; the reference's engine decodes every column first "
+                   "(decode_only_ms per column) and then hashes 60 M rows on the CPU")
+    ctx.close()
+    return out
+
+
 def c1_lookups(adac, wl, n=10_000_000, nlookups=10_000):
     """C1 (benchmark/micro/succinct/zipf_distribution.cpp:13-48): t1(i UINTEGER) with i = 0..N-1, compacted, then
     `SELECT i FROM t1 WHERE i == k` for Zipf(N, 1.0) keys (mt19937, seed 42).  Each look-up is one fused
@@ -333,7 +401,7 @@ def main():
     wl = importlib.import_module(PKG + ".workload")
     only = sys.argv[1:]
     jobs = {"plugin_scan": lambda: plugin_scan(host, lay), "adaptive": lambda: adaptive(host, wl),
-            "bitpacking_scan": lambda: bitpacking_scan(adac), "q6_packed": lambda: q6_packed(adac),
+            "bitpacking_scan": lambda: bitpacking_scan(adac), "q6_packed": lambda: q6_packed(adac), "q1_packed": lambda: q1_packed(adac),
             "c1_lookups": lambda: c1_lookups(adac, wl)}
     res = {k: f() for k, f in jobs.items() if not only or k in only}
     print(json.dumps(res))

@@ -151,6 +151,7 @@ SIGNATURES = {
     "adac_graph_launch": (_int, [_vp]),
     "adac_graph_destroy": (None, [_vp]),
     "adac_scan_sum": (_int, [_vp, _vp, _vp]),
+    "adac_scan_group_sum": (_int, [_vp, _vp, _vp, _vp, _u32, _vp, _vp]),
     "adac_scan_count_eq": (_int, [_vp, _vp, _u64, _vp]),
     "adac_scan_count_between": (_int, [_vp, _vp, _u64, _u64, _vp]),
     "adac_scan_sum_valid": (_int, [_vp, _vp, _vp, _vp]),
@@ -544,6 +545,11 @@ class Layout:
 
     def scan_sum(self, d_words, d_sums, d_validity=None):
         _check(lib().adac_scan_sum_valid(self._h, _dptr(d_words), _dptr(d_validity), _dptr(d_sums)), "adac_scan_sum")
+
+    def scan_group_sum(self, d_words, keys, d_key_words, ngroups, d_sums, d_counts):
+        """SUM(self) and COUNT(*) GROUP BY `keys` (a Layout over the same rows); ngroups + 1 results each."""
+        _check(lib().adac_scan_group_sum(self._h, _dptr(d_words), keys._h, _dptr(d_key_words), int(ngroups),
+                                         _dptr(d_sums), _dptr(d_counts)), "adac_scan_group_sum")
 
     def scan_count_between(self, d_words, lo, hi, d_counts, d_validity=None):
         """lo / hi: bit patterns of the column type (use int(np.array([v], dtype).view(unsigned)[0]) for signed)."""

@@ -77,6 +77,7 @@ struct adac_layout {
 	uint32_t *d_tile_cnt = nullptr;
 	uint64_t *d_tile_off = nullptr;
 	uint64_t *d_block_tot = nullptr;
+	void *d_group_partial = nullptr; // per-workgroup partials of adac_scan_group_sum (allocated on first use)
 };
 
 static adac_status descs_changed(adac_layout *l);
@@ -328,6 +329,7 @@ extern "C" int adac_set_tuning(const char *name, int value) {
 	else if (n == "single_pass_encode") adac::g_tuning.single_pass_encode = value;
 	else if (n == "encode_stamps") adac::g_tuning.encode_stamps = value;
 	else if (n == "encode_placement") adac::g_tuning.encode_placement = value;
+	else if (n == "group_sum_wide") adac::g_tuning.group_sum_wide = value;
 	else if (n == "templated_scan") adac::g_tuning.templated_scan = value;
 	else if (n == "scan_tiles_per_wg" && value >= 0) adac::g_tuning.scan_tiles_per_wg = value; // 0 = by type
 	else if (n == "blocks_per_cu" && value > 0) adac::g_tuning.blocks_per_cu = value;
@@ -614,6 +616,7 @@ extern "C" void adac_layout_destroy(adac_layout *l) {
 	if (l->d_group_refs) (void)hipFree(l->d_group_refs);
 	if (l->d_groups) (void)hipFree(l->d_groups);
 	if (l->d_scan_state) (void)hipFree(l->d_scan_state);
+	if (l->d_group_partial) (void)hipFree(l->d_group_partial);
 	adac_ctx *c = l->ctx;
 	delete l;
 	ctx_release(c);
@@ -983,6 +986,23 @@ extern "C" adac_status adac_scan_sum_valid(adac_layout *l, const uint64_t *d_wor
 	if (gst != ADAC_OK) return gst;
 	ADAC_HIP(adac::launch_scan_sum(l->ctx->stream, l->type_size, l->d_groups, l->ngroups, d_words, d_validity, sbit,
 	                               d_sums));
+	return ADAC_OK;
+}
+
+// SUM(value), COUNT(*) GROUP BY key over two packed columns of one table (Q1's shape, TPCH_runtime.txt:2-6)
+extern "C" adac_status adac_scan_group_sum(adac_layout *values, const uint64_t *d_value_words, adac_layout *keys,
+                                           const uint64_t *d_key_words, uint32_t ngroups, uint64_t *d_sums,
+                                           uint64_t *d_counts) {
+	if (!values || !keys || values->ctx != keys->ctx || !d_sums || !d_counts) return ADAC_ERR_INVALID_ARGUMENT;
+	if (ngroups == 0 || ngroups > adac::group_sum_max_groups()) return ADAC_ERR_INVALID_ARGUMENT;
+	if (values->counts != keys->counts) return ADAC_ERR_INVALID_ARGUMENT; // the same rows, segment by segment
+	if (values->total_values && (!d_value_words || !d_key_words)) return ADAC_ERR_INVALID_ARGUMENT;
+	if (!aligned16(d_value_words) || !aligned16(d_key_words)) return ADAC_ERR_INVALID_ARGUMENT;
+	ADAC_HIP(hipSetDevice(values->ctx->device));
+	if (!values->d_group_partial) ADAC_HIP(hipMalloc(&values->d_group_partial, adac::group_sum_partial_bytes()));
+	ADAC_HIP(adac::launch_group_sum(values->ctx->stream, values->type_size, values->is_signed, keys->type_size,
+	                                values->d_descs, values->d_tiles, values->ntiles, d_value_words, keys->d_descs,
+	                                d_key_words, ngroups, values->d_group_partial, d_sums, d_counts));
 	return ADAC_OK;
 }
 

@@ -1777,6 +1777,7 @@ hipError_t dispatch_size(uint32_t type_size, F &&f) {
 #include "adac_select_gather.inl"
 #include "adac_block_image.inl"
 #include "adac_encode_1p.inl"
+#include "adac_group_sum.inl"
 
 unsigned persistent_grid(uint64_t ntiles) {
 	const uint64_t cap = (uint64_t)g_tuning.num_cus * (uint64_t)g_tuning.blocks_per_cu;
@@ -1867,6 +1868,35 @@ hipError_t launch_encode_1p(hipStream_t s, uint32_t type_size, bool sign_extend,
 		                   state, reinterpret_cast<uint32_t *>(state + nseg), d_words, g_tuning.encode_stamps, g_tuning.encode_placement);
 		return hipGetLastError();
 	});
+}
+
+uint64_t group_sum_partial_bytes() { return (uint64_t)kGroupMaxWorkgroups * 2u * kGroupMaxBins * sizeof(unsigned long long); }
+uint32_t group_sum_max_groups() { return kGroupMaxBins - 1u; }
+
+hipError_t launch_group_sum(hipStream_t s, uint32_t v_type_size, bool v_signed, uint32_t k_type_size,
+                            const adac_segment_desc *d_vdescs, const TileRef *d_vtiles, uint64_t ntiles,
+                            const uint64_t *d_vwords, const adac_segment_desc *d_kdescs, const uint64_t *d_kwords,
+                            uint32_t ngroups, void *d_partial, uint64_t *d_sums, uint64_t *d_counts) {
+	GroupSumTypes ty;
+	ty.v_tmask = v_type_size >= 8 ? ~0ull : ((1ull << (8 * v_type_size)) - 1ull);
+	ty.v_sbit = v_signed ? (1ull << (8 * v_type_size - 1)) : 0ull;
+	ty.k_tmask = k_type_size >= 8 ? ~0ull : ((1ull << (8 * k_type_size)) - 1ull);
+	ty.v_tile_rows = tile_values(v_type_size);
+	ty.wide_only = g_tuning.group_sum_wide ? 1u : 0u;
+	// persistent: as many workgroups as are resident at once (three per CU: 41 KiB of LDS each), so nobody runs a
+	// second round on a third of the chip
+	uint64_t cap = 3ull * (uint64_t)(g_tuning.num_cus > 0 ? g_tuning.num_cus : 256);
+	cap = cap < kGroupMaxWorkgroups ? cap : kGroupMaxWorkgroups;
+	const uint32_t nwg = (uint32_t)(ntiles < cap ? ntiles : cap);
+	unsigned long long *partial = static_cast<unsigned long long *>(d_partial);
+	if (nwg) {
+		hipLaunchKernelGGL(k_group_sum, dim3(nwg), dim3(kWorkgroup), 0, s, d_vdescs, d_vtiles, (uint32_t)ntiles, d_vwords,
+		                   d_kdescs, d_kwords, ty, ngroups, partial);
+		hipError_t e = hipGetLastError();
+		if (e != hipSuccess) return e;
+	}
+	hipLaunchKernelGGL(k_group_final, dim3(ngroups + 1u), dim3(64), 0, s, partial, nwg, ngroups + 1u, d_sums, d_counts);
+	return hipGetLastError();
 }
 
 hipError_t read_encode_stamps(void *host, uint64_t bytes) {

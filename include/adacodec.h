@@ -339,6 +339,17 @@ adac_status adac_scan_count_eq(adac_layout *l, const uint64_t *d_words, uint64_t
 adac_status adac_scan_count_between(adac_layout *l, const uint64_t *d_words, uint64_t lo, uint64_t hi,
                                     uint64_t *d_counts);
 
+/* Grouped aggregate over TWO packed columns of one table — the shape of TPC-H Q1 on the reference's config 3
+ * (`SELECT key, SUM(value), COUNT(*) ... GROUP BY key`, benchmark log TPCH_runtime.txt:2-6; the reference decodes both
+ * columns vector by vector, succinct.cpp:123-144, and feeds a hash aggregate).  `values` and `keys` are layouts on the
+ * same context with the same row count per segment (types, widths, placements may differ); nothing is materialised.
+ * key = the key column's value as an unsigned number of its own width.  d_sums[g], d_counts[g] for g < ngroups are the
+ * sum (values widened to 64 bits by the value type's signedness, mod 2^64 — adac_scan_sum's rule) and the number of
+ * the rows whose key is g; entry [ngroups] collects the rows whose key is >= ngroups, so both arrays hold ngroups + 1
+ * entries.  1 <= ngroups <= 256. */
+adac_status adac_scan_group_sum(adac_layout *values, const uint64_t *d_value_words, adac_layout *keys,
+                                const uint64_t *d_key_words, uint32_t ngroups, uint64_t *d_sums, uint64_t *d_counts);
+
 /* The same two scans with a DuckDB validity mask over the element index space (bit e of word e/64 set = row e
  * valid, as for adac_analyze): NULL rows take no part in the aggregate — what SUM / COUNT over a nullable
  * column mean.  d_validity == NULL is the unmasked scan. */
