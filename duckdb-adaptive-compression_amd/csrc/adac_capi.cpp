@@ -77,6 +77,8 @@ struct adac_layout {
 	uint32_t *d_tile_cnt = nullptr;
 	uint64_t *d_tile_off = nullptr;
 	uint64_t *d_block_tot = nullptr;
+	void *d_sel_edges = nullptr;     // shared-word records of the selection scan (two per scan group)
+	uint64_t sel_edges_groups = 0;   // ... sized for this many groups
 	void *d_group_partial = nullptr; // per-workgroup partials of adac_scan_group_sum (allocated on first use)
 };
 
@@ -617,6 +619,7 @@ extern "C" void adac_layout_destroy(adac_layout *l) {
 	if (l->d_groups) (void)hipFree(l->d_groups);
 	if (l->d_scan_state) (void)hipFree(l->d_scan_state);
 	if (l->d_group_partial) (void)hipFree(l->d_group_partial);
+	if (l->d_sel_edges) (void)hipFree(l->d_sel_edges);
 	adac_ctx *c = l->ctx;
 	delete l;
 	ctx_release(c);
@@ -1026,24 +1029,34 @@ static adac_status scan_range(adac_layout *l, const uint64_t *d_words, const uin
 	const uint64_t umask = bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);
 	const uint64_t sbit = l->is_signed ? (1ull << (bits - 1)) : 0ull;
 	const uint64_t blo = (lo & umask) ^ sbit, bhi = (hi & umask) ^ sbit;
-	// The scan writes every bitmap word that lies inside a group whole (zero words included) and ORs only into the
-	// words two groups share.  With the segments back to back in the value space that covers the whole bitmap, so
-	// only those shared words are zeroed first (a tiny kernel instead of a full clearing pass: 12.5 MB at C2);
-	// value spaces with gaps between segments, and the empty range, take the full memset.
-	const bool edges_only = want_bitmap && l->dense_values && bhi >= blo && l->ntiles;
+	// The scan writes every bitmap word that lies inside a group whole (zero words included).  With the segments back
+	// to back in the value space the words two groups share are all that is left: every group leaves its bits of
+	// them in a record, and a tiny kernel ORs the records of a word and stores it afterwards — no clearing pass
+	// (12.5 MB at C2) and no global atomics.  Value spaces with gaps between segments, and the empty range, take the
+	// full memset and atomicOr.
+	// (A/B: sel_debug 5 takes the memset + atomicOr form on a dense value space too)
+	const bool edges_only = want_bitmap && l->dense_values && bhi >= blo && l->ntiles && adac::g_tuning.sel_debug != 5;
 	if (want_bitmap && l->value_span && !edges_only) {
 		ADAC_HIP(hipMemsetAsync(d_bitmap, 0, ((l->value_span + 63) / 64) * sizeof(uint64_t), l->ctx->stream));
 	}
 	if (bhi < blo) return ADAC_OK; // empty range: all counts (and bits) stay zero
 	adac_status gst = ensure_scan_groups(l);
 	if (gst != ADAC_OK) return gst;
-	if (edges_only) {
-		const uint64_t words32 = (l->value_span + 31) / 32; // the odd half of the last 64-bit word, if there is one
-		ADAC_HIP(adac::launch_sel_clear_edges(l->ctx->stream, l->d_groups, l->ngroups, d_bitmap,
-		                                      (words32 & 1) ? words32 : ~0ull));
+	if (edges_only && l->sel_edges_groups < l->ngroups) {
+		if (l->d_sel_edges) ADAC_HIP(hipFree(l->d_sel_edges));
+		l->d_sel_edges = nullptr;
+		l->sel_edges_groups = 0;
+		ADAC_HIP(hipMalloc(&l->d_sel_edges, adac::sel_edge_bytes(l->ngroups)));
+		l->sel_edges_groups = l->ngroups;
 	}
 	ADAC_HIP(adac::launch_scan_count_range(l->ctx->stream, l->type_size, l->d_groups, l->ngroups, d_words, d_validity,
-	                                       blo, bhi - blo, sbit, d_counts, want_bitmap ? d_bitmap : nullptr));
+	                                       blo, bhi - blo, sbit, d_counts, want_bitmap ? d_bitmap : nullptr,
+	                                       edges_only ? l->d_sel_edges : nullptr));
+	if (edges_only) {
+		const uint64_t words32 = (l->value_span + 31) / 32; // the odd half of the last 64-bit word, if there is one
+		ADAC_HIP(adac::launch_sel_merge_edges(l->ctx->stream, l->d_sel_edges, l->ngroups, d_bitmap,
+		                                      (words32 & 1) ? words32 : ~0ull));
+	}
 	return ADAC_OK;
 }
 

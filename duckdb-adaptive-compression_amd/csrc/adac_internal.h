@@ -140,11 +140,12 @@ hipError_t launch_gather_selected(hipStream_t s, uint32_t type_size, const adac_
                                   uint64_t *d_block_tot, void *d_out, uint64_t *d_out_ids, uint64_t *d_total);
 hipError_t launch_scan_sum(hipStream_t s, uint32_t type_size, const ScanGroup *d_groups, uint64_t ngroups,
                            const uint64_t *d_words, const uint64_t *d_validity, uint64_t sbit, uint64_t *d_sums);
-hipError_t launch_sel_clear_edges(hipStream_t s, const ScanGroup *d_groups, uint64_t ngroups, uint64_t *d_bitmap,
+uint64_t sel_edge_bytes(uint64_t ngroups);
+hipError_t launch_sel_merge_edges(hipStream_t s, const void *d_edges, uint64_t ngroups, uint64_t *d_bitmap,
                                   uint64_t tail_word);
 hipError_t launch_scan_count_range(hipStream_t s, uint32_t type_size, const ScanGroup *d_groups, uint64_t ngroups,
                                    const uint64_t *d_words, const uint64_t *d_validity, uint64_t blo, uint64_t bspan,
-                                   uint64_t sbit, uint64_t *d_counts, uint64_t *d_bitmap);
+                                   uint64_t sbit, uint64_t *d_counts, uint64_t *d_bitmap, void *d_edges);
 
 // Persistent block images (adac_block_image.inl): one segment's packed words <-> its image in a block buffer.
 struct BlockJob {

@@ -354,6 +354,15 @@ __device__ __forceinline__ uint32_t field_of(const uint32_t (&nrm)[5], int j) {
 	return __builtin_amdgcn_alignbit(nrm[d + 1], nrm[d], sh) & mask;
 }
 
+// A bitmap word two scan groups share: each group leaves its bits in a record of its own, k_sel_merge_edges ORs the
+// records of a word and stores it.  (A global atomicOr per shared word cost 13 % of the selection scan at w = 8:
+// two L2 round trips at the end of every workgroup, profiles/r02_select_writeout_ablation.json.)
+struct SelEdge {
+	uint64_t word; // index of the 32-bit bitmap word
+	uint32_t bits;
+	uint32_t valid;
+};
+
 // ---------------------------------------------------------------------------------------------
 // Selection-bitmap output of the filter scan (OP 3).  A workgroup owns the rows [first, first + n) of ONE segment
 // (its ScanGroup), i.e. one contiguous bit string of the result.  Lanes OR their hit bits into a zeroed LDS image
@@ -372,6 +381,7 @@ struct SelOut {
 	uint32_t *bitmap32; // the output bitmap viewed as little-endian 32-bit words
 	uint32_t p_base;    // position of bit 0 of the image: ((val_off & 31) + first) & ~31
 	int debug;          // diagnostic (adac_set_tuning "sel_debug"): 1 = no write-out, 2 = no emit at all (results wrong)
+	SelEdge *edges;     // dense value spaces: the group's two records for the words it shares (nullptr: global atomicOr)
 };
 
 __device__ __forceinline__ void sel_or(const SelOut &o, uint32_t p, uint32_t bits, uint32_t nbits) {
@@ -392,8 +402,27 @@ __device__ __forceinline__ void sel_write_out(const SelOut &o, uint32_t *__restr
 		uint32_t *g = seg_words32 + (wb >> 5);
 		if (wb >= p0 && wb + 32u <= p1) {
 			*g = v;
+		} else if (o.edges) { // only the first and the last word of the group can be shared
+			SelEdge e;
+			e.word = (uint64_t)(g - o.bitmap32);
+			e.bits = v;
+			e.valid = 1u;
+			o.edges[i == 0u ? 0 : 1] = e;
 		} else if (v) {
 			atomicOr(g, v);
+		}
+	}
+	if (o.edges && threadIdx.x < 2u) { // the slots this group does not need say so (slot 1 also when nwords <= 1)
+		const uint32_t last = nwords ? nwords - 1u : 0u;
+		const uint32_t i = threadIdx.x == 0u ? 0u : last;
+		const uint32_t wb = o.p_base + 32u * i;
+		const bool whole = nwords == 0u || (wb >= p0 && wb + 32u <= p1);
+		if (whole || (threadIdx.x == 1u && last == 0u)) {
+			SelEdge e;
+			e.word = 0;
+			e.bits = 0;
+			e.valid = 0u;
+			o.edges[threadIdx.x] = e;
 		}
 	}
 }
@@ -645,17 +674,36 @@ __global__ void k_expand_groups(const adac_segment_desc *__restrict__ descs, con
 	groups[g] = out;
 }
 
-// Before a selection scan over a DENSE value space (segments back to back): zero only the bitmap words two groups
-// may share — a group's first and last word when its range does not start / end on a word boundary — and the odd
-// 32-bit half of the last 64-bit word.  Everything else is written whole by the scan itself.
-__global__ void k_sel_clear_edges(const ScanGroup *__restrict__ groups, uint64_t ngroups, uint32_t *__restrict__ bitmap32,
+// After a selection scan over a DENSE value space (segments back to back): the words two or more groups share.  The
+// scan wrote every word that lies inside one group whole and left two records per group for its first / last word
+// when they are partial; records of one word are near neighbours in group order (slots that are not needed lie
+// between them).  The first record of a word ORs its followers and stores the word; thread 0 also zeroes the odd 32-bit
+// half of the last 64-bit word.  No atomics, and no clearing pass before the scan.
+__global__ void k_sel_merge_edges(const SelEdge *__restrict__ edges, uint64_t nrec, uint32_t *__restrict__ bitmap32,
                                   uint64_t tail_word) {
-	const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (g == 0 && tail_word != ~0ull) bitmap32[tail_word] = 0u;
-	if (g >= ngroups) return;
-	const uint64_t p0 = groups[g].d.val_off + groups[g].first, p1 = p0 + groups[g].n;
-	if (p0 & 31u) bitmap32[p0 >> 5] = 0u;
-	if (p1 & 31u) bitmap32[p1 >> 5] = 0u;
+	const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r == 0 && tail_word != ~0ull) bitmap32[tail_word] = 0u;
+	if (r >= nrec) return;
+	const SelEdge me = edges[r];
+	if (!me.valid) return;
+	// a word holds 32 rows and a group at least one: the records of one word lie within 64 slots of each other (the
+	// runs of unused slots between the records of DIFFERENT words can be long: the searches are bounded)
+	const uint64_t lo = r > 64 ? r - 64 : 0, hi = r + 64 < nrec ? r + 64 : nrec - 1;
+	for (uint64_t p = r; p > lo;) { // is an earlier record of the same word there?  (skip the unused slots)
+		--p;
+		const SelEdge q = edges[p];
+		if (!q.valid) continue;
+		if (q.word == me.word) return; // not the first one
+		break;
+	}
+	uint32_t bits = me.bits;
+	for (uint64_t p = r + 1; p <= hi; p++) {
+		const SelEdge q = edges[p];
+		if (!q.valid) continue;
+		if (q.word != me.word) break;
+		bits |= q.bits;
+	}
+	bitmap32[me.word] = bits;
 }
 
 // OP 0: SUM, 1: COUNT(lo <= v <= hi), 2: load-only probe, 3: COUNT + selection bitmap; V: validity mask given.
@@ -664,7 +712,8 @@ template <typename U, int OP, bool V>
 __global__ __launch_bounds__(kWorkgroup, 6) void k_scan_agg(const ScanGroup *__restrict__ groups, int templated,
                                                             const uint64_t *__restrict__ words, RangePred pred,
                                                             const uint64_t *__restrict__ validity,
-                                                            uint64_t *__restrict__ result, uint32_t *__restrict__ bitmap32) {
+                                                            uint64_t *__restrict__ result, uint32_t *__restrict__ bitmap32,
+                                                            SelEdge *__restrict__ edges) {
 	// LDS: the packed image of one stage of the fallback path (the register path uses none) and, for the selection
 	// scan, the bitmap image of the group.  The selection scan halves the stage so that both fit 16.4 KiB: at
 	// 24.6 KiB only six workgroups fit a CU instead of eight, and these kernels are bound by the bytes a CU keeps
@@ -676,7 +725,7 @@ __global__ __launch_bounds__(kWorkgroup, 6) void k_scan_agg(const ScanGroup *__r
 	const uint32_t *lds32 = reinterpret_cast<const uint32_t *>(lds);
 	const ScanGroup g = groups[blockIdx.x];
 	const adac_segment_desc &d = g.d;
-	SelOut sel_out {sel_img, bitmap32, 0u, templated >> 1};
+	SelOut sel_out {sel_img, bitmap32, 0u, templated >> 1, edges ? edges + 2u * (uint64_t)blockIdx.x : nullptr};
 	templated &= 1;
 	const uint32_t sel_p0 = (uint32_t)(d.val_off & 31u) + g.first; // the group's positions [sel_p0, sel_p0 + n)
 	if (OP == 3) {
@@ -1999,38 +2048,41 @@ hipError_t launch_scan_sum(hipStream_t s, uint32_t type_size, const ScanGroup *d
 		uint32_t *no_bitmap = nullptr;
 		if (g_tuning.scan_probe) { // diagnostic: the scan's loop and loads without the field walk (result meaningless)
 			hipLaunchKernelGGL((k_scan_agg<U, 2, false>), grid, dim3(kWorkgroup), 0, s, d_groups, 1, d_words, RangePred {},
-			                   static_cast<const uint64_t *>(nullptr), d_sums, no_bitmap);
+			                   static_cast<const uint64_t *>(nullptr), d_sums, no_bitmap, static_cast<SelEdge *>(nullptr));
 		} else if (d_validity) {
 			hipLaunchKernelGGL((k_scan_agg<U, 0, true>), grid, dim3(kWorkgroup), 0, s, d_groups, tpl, d_words, widen,
-			                   d_validity, d_sums, no_bitmap);
+			                   d_validity, d_sums, no_bitmap, static_cast<SelEdge *>(nullptr));
 		} else {
 			hipLaunchKernelGGL((k_scan_agg<U, 0, false>), grid, dim3(kWorkgroup), 0, s, d_groups, tpl, d_words, widen,
-			                   d_validity, d_sums, no_bitmap);
+			                   d_validity, d_sums, no_bitmap, static_cast<SelEdge *>(nullptr));
 		}
 		return hipGetLastError();
 	});
 }
 
-hipError_t launch_sel_clear_edges(hipStream_t s, const ScanGroup *d_groups, uint64_t ngroups, uint64_t *d_bitmap,
+uint64_t sel_edge_bytes(uint64_t ngroups) { return 2 * ngroups * sizeof(SelEdge); }
+
+hipError_t launch_sel_merge_edges(hipStream_t s, const void *d_edges, uint64_t ngroups, uint64_t *d_bitmap,
                                   uint64_t tail_word) {
-	hipLaunchKernelGGL(k_sel_clear_edges, dim3((unsigned)((ngroups + 255) / 256 + (ngroups == 0))), dim3(256), 0, s,
-	                   d_groups, ngroups, reinterpret_cast<uint32_t *>(d_bitmap), tail_word);
+	const uint64_t nrec = 2 * ngroups;
+	hipLaunchKernelGGL(k_sel_merge_edges, dim3((unsigned)((nrec + 255) / 256 + (nrec == 0))), dim3(256), 0, s,
+	                   static_cast<const SelEdge *>(d_edges), nrec, reinterpret_cast<uint32_t *>(d_bitmap), tail_word);
 	return hipGetLastError();
 }
 
 hipError_t launch_scan_count_range(hipStream_t s, uint32_t type_size, const ScanGroup *d_groups, uint64_t ngroups,
                                    const uint64_t *d_words, const uint64_t *d_validity, uint64_t blo, uint64_t bspan,
-                                   uint64_t sbit, uint64_t *d_counts, uint64_t *d_bitmap) {
+                                   uint64_t sbit, uint64_t *d_counts, uint64_t *d_bitmap, void *d_edges) {
 	if (ngroups == 0) return hipSuccess;
 	return dispatch_size(type_size, [&](auto tag) {
 		using U = decltype(tag);
 		const dim3 grid((unsigned)ngroups);
 		const RangePred pred {blo, bspan, sbit};
 		uint32_t *bm = reinterpret_cast<uint32_t *>(d_bitmap);
-		const int tpl = g_tuning.templated_scan | (g_tuning.sel_debug << 1);
+		const int tpl = g_tuning.templated_scan | ((g_tuning.sel_debug == 5 ? 0 : g_tuning.sel_debug) << 1);
 #define ADAC_SCAN(OPN, VAL)                                                                                            \
 	hipLaunchKernelGGL((k_scan_agg<U, OPN, VAL>), grid, dim3(kWorkgroup), 0, s, d_groups, tpl, d_words, pred,         \
-	                   d_validity, d_counts, bm)
+	                   d_validity, d_counts, bm, static_cast<SelEdge *>(d_edges))
 		if (d_bitmap) {
 			if (d_validity) ADAC_SCAN(3, true); else ADAC_SCAN(3, false);
 		} else {

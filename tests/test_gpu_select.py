@@ -263,3 +263,29 @@ def test_pipeline_replayed_as_a_hip_graph(adac, oracle, gpu_ctx):
     gpu_ctx.sync()
     assert int(d_sum.download(np.uint64, len(counts)).sum(dtype=np.uint64)) == int(b2[(a >= 100) & (a <= 299)].astype(np.uint64).sum())
     g.close()
+
+
+@pytest.mark.parametrize("dtype", [np.uint64, np.int32, np.uint16, np.uint8])
+def test_select_bitmap_words_shared_by_many_groups(adac, oracle, gpu_ctx, dtype):
+    """Dense value space (segments back to back): the scan writes the words inside a group whole and leaves a record
+    for every word it shares; k_sel_merge_edges ORs the records of a word.  Runs of tiny segments put up to 32 groups
+    into one bitmap word, segments that end exactly on word boundaries leave unused record slots between them, and
+    the last word may be the odd half of a 64-bit word."""
+    dtype = np.dtype(dtype)
+    rng = np.random.default_rng(4242 + dtype.itemsize)
+    tile = adac.tile_values(dtype)
+    counts = ([1] * 70 + [32, 32, 64, 1, 31, 33, 2, 30, 5] + [int(x) for x in rng.integers(1, 40, size=150)] +
+              [2 * tile, 3, tile + 17, 1, 1, 1, 64, 5 * tile + 31, 7] + [int(x) for x in rng.integers(1, 6, size=200)] + [29])
+    segs = [make_values(rng, dtype, n, int(rng.integers(1, min(8 * dtype.itemsize, 20)))) for n in counts]
+    counts = np.array(counts, dtype=np.uint32)
+    lay, d_words, _, _, _ = run_encode_decode(adac, oracle, gpu_ctx, dtype, counts, segs)
+    offs = np.concatenate([[0], np.cumsum(counts[:-1])]).astype(np.int64).tolist()
+    span = int(counts.sum())
+    assert lay.value_span == span
+    info = np.iinfo(dtype)
+    big = segs[int(np.argmax(counts))]
+    probes = [(int(info.min), int(info.max)), (int(np.median(big)), int(info.max)), (int(info.min), int(np.median(big))),
+              (int(big[0]), int(big[0]))]
+    check_select(adac, gpu_ctx, lay, d_words, dtype, segs, offs, span, probes)
+    valid = rng.random(span) > 0.3
+    check_select(adac, gpu_ctx, lay, d_words, dtype, segs, offs, span, probes[:2], valid)
