@@ -482,8 +482,8 @@ def main():
         result["fused_scan"]["select_bitmap"] = {
             "kernel": "k_scan_agg<u64,select>", "values_per_s": my_rows / (ms_sel * 1e-3), "ms": ms_sel,
             "read_GBps": rd / (ms_sel * 1e-3) / 1e9, "bitmap_bytes": (my_rows + 7) // 8,
-            "note": "includes the tiny kernel that zeroes the bitmap words two scan groups share (no full clearing pass: "
-                    "the scan writes every other word whole)",
+            "note": "includes the tiny kernel that merges the bitmap words two scan groups share (no clearing pass, "
+                    "no global atomics: the scan writes every other word whole)",
         }
         # scan-with-selection: decode only the rows the bitmap keeps (dense output + element ids)
         nsel = int((vals <= median).sum())
