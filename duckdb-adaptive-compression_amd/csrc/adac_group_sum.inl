@@ -5,18 +5,23 @@
 // group-by sum"): the engine decodes both columns vector by vector (SuccinctScanPartial, succinct.cpp:123-144) and
 // feeds a hash aggregate.  Here nothing is materialised: a workgroup walks tiles of the VALUE column's layout, stages
 // the packed bits of the same rows of both columns in LDS, and every thread adds its rows into LDS bins:
-//   * up to kGroupPrivateBins bins (Q1: 4 - 6 groups + the overflow bin): one bin set PER THREAD, bins[b][thread] — a
-//     wave's 64 lanes touch 64 different addresses whatever the keys are, so the adds never collide;
+//   * up to kGroupPrivateBins bins (Q1: 4 - 6 groups + the overflow bin): SIXTEEN bin sets per wave, bins[b][set] with
+//     set = lane & 15 — at most four lanes collide on an LDS add whatever the keys are.  (One set per THREAD never
+//     collides but costs 24 KiB per workgroup: three workgroups per CU, and the kernel — a chain of LDS and global
+//     round trips per stage — ran at the same 0.21 ms per 60 M-row column whatever was done to its loops; with
+//     6 KiB of bins seven workgroups fit and it runs 0.085 - 0.14 ms: profiles/r02_q1_packed.json);
 //   * up to kGroupMaxBins bins: one bin set per workgroup, LDS atomics (collisions serialise when few keys dominate).
 // A workgroup is persistent (grid-stride over the tiles) and carries its bins across tiles; at the end it writes ONE
 // partial {sum, count} per bin, and k_group_final adds the partials — no global atomics on a handful of addresses.
 // Semantics: key = the key column's value as an unsigned number of its own width; rows whose key >= ngroups land in
 // bin `ngroups`.  SUM = the values widened to 64 bits by the value type's signedness, mod 2^64 (adac_scan_sum's rule).
 
-constexpr uint32_t kGroupStageBytes = 3584;   // packed bytes of one column per stage: at most one 16-byte chunk per thread
+constexpr uint32_t kGroupStageBytes = 3584;   // packed bytes of one column per stage
+constexpr uint32_t kGroupChunksPerThread = (kGroupStageBytes / 16 + 1 + kWorkgroup - 1) / kWorkgroup;
+constexpr uint32_t kGroupCopies = 16;         // bin sets per wave (lane & 15 picks one): 4 lanes share a set (8 sets: slower)
 constexpr uint32_t kGroupPrivateBins = 8;     // bins held per thread
 constexpr uint32_t kGroupMaxBins = 257;       // 256 groups + overflow
-constexpr uint32_t kGroupMaxWorkgroups = 1024; // capacity of the partial buffer; the launch uses 3 per CU (41 KiB of LDS each)
+constexpr uint32_t kGroupMaxWorkgroups = 2048; // capacity of the partial buffer; the launch uses 7 per CU (21 KiB of LDS each)
 
 // the w-bit field at `bit` of a staged image, any w in 1..64: mlo / mhi = the low / high dword of the width mask.
 // Branch-free on purpose (three dwords are always read): a branch on the width ends the basic block, the compiler
@@ -76,12 +81,16 @@ __global__ __launch_bounds__(kWorkgroup) void k_group_sum(const adac_segment_des
 	// aggregated and written to the other buffer after it, so a global round trip is always in flight
 	__shared__ uint4 vstage[2][kGroupStageBytes / 16 + 2];
 	__shared__ uint4 kstage[2][kGroupStageBytes / 16 + 2];
-	__shared__ unsigned long long bsum[kGroupPrivateBins * kWorkgroup];
-	__shared__ uint32_t bcnt[kGroupPrivateBins * kWorkgroup];
+	// bins: up to kGroupPrivateBins bins in kGroupCopies sets per wave, or one set of up to kGroupMaxBins bins
+	constexpr uint32_t kSets = (kWorkgroup / 64) * kGroupCopies;
+	constexpr uint32_t kBinSlots = kGroupPrivateBins * kSets > kGroupMaxBins ? kGroupPrivateBins * kSets : kGroupMaxBins;
+	__shared__ unsigned long long bsum[kBinSlots];
+	__shared__ uint32_t bcnt[kBinSlots];
+	const uint32_t my_set = (threadIdx.x >> 6) * kGroupCopies + (threadIdx.x & (kGroupCopies - 1u));
 	const uint32_t nbins = ngroups + 1u;
 	const bool priv = nbins <= kGroupPrivateBins; // uniform
 	const uint32_t tid = threadIdx.x;
-	for (uint32_t i = tid; i < kGroupPrivateBins * kWorkgroup; i += kWorkgroup) {
+	for (uint32_t i = tid; i < kBinSlots; i += kWorkgroup) {
 		bsum[i] = 0ull;
 		bcnt[i] = 0u;
 	}
@@ -134,7 +143,7 @@ __global__ __launch_bounds__(kWorkgroup) void k_group_sum(const adac_segment_des
 		g.ksrc = reinterpret_cast<const uint4 *>(kwords + mcur.kd.word_off) + (kpos >> 7);
 		g.vbit0 = (uint32_t)(vpos & 127);
 		g.kbit0 = (uint32_t)(kpos & 127);
-		g.vchunks = (g.vbit0 + g.m * g.wv + 127u) >> 7; // <= kGroupStageBytes / 16 + 1 <= one per thread
+		g.vchunks = (g.vbit0 + g.m * g.wv + 127u) >> 7; // <= kGroupStageBytes / 16 + 1 <= two per thread, >= 1
 		g.kchunks = (g.kbit0 + g.m * g.wk + 127u) >> 7;
 		g.vadd = effective_add(mcur.vd);
 		g.kadd = effective_add(mcur.kd);
@@ -143,18 +152,27 @@ __global__ __launch_bounds__(kWorkgroup) void k_group_sum(const adac_segment_des
 	};
 	GroupStage cur, nxt;
 	bool have = next_stage(cur); // uniform
-	uint4 vq = make_uint4(0, 0, 0, 0), kq = make_uint4(0, 0, 0, 0);
+	uint4 vq[kGroupChunksPerThread], kq[kGroupChunksPerThread];
 	if (have) {
-		if (tid < cur.vchunks) vstage[0][tid] = cur.vsrc[tid]; // chunks <= kGroupStageBytes / 16 + 1: inside the buffer
-		if (tid < cur.kchunks) kstage[0][tid] = cur.ksrc[tid];
+#pragma unroll
+		for (uint32_t h = 0; h < kGroupChunksPerThread; h++) { // chunks <= kGroupStageBytes / 16 + 1: inside the buffer
+			const uint32_t c = tid + h * kWorkgroup;
+			if (c < cur.vchunks) vstage[0][c] = cur.vsrc[c];
+			if (c < cur.kchunks) kstage[0][c] = cur.ksrc[c];
+		}
 	}
 	__syncthreads();
 	uint32_t buf = 0;
 	while (have) {
 		const bool more = next_stage(nxt);
-		if (more) { // in flight while this stage is aggregated
-			vq = tid < nxt.vchunks ? nxt.vsrc[tid] : vq;
-			kq = tid < nxt.kchunks ? nxt.ksrc[tid] : kq;
+		if (more) { // in flight while this stage is aggregated.  UNCONDITIONAL loads (index clamped into the stage): a
+			// load under a per-lane condition gets a wait of its own and the round trips run one after the other
+#pragma unroll
+			for (uint32_t h = 0; h < kGroupChunksPerThread; h++) {
+				const uint32_t c = tid + h * kWorkgroup;
+				vq[h] = nxt.vsrc[c < nxt.vchunks ? c : nxt.vchunks - 1u];
+				kq[h] = nxt.ksrc[c < nxt.kchunks ? c : nxt.kchunks - 1u];
+			}
 		}
 		const uint32_t *v32 = reinterpret_cast<const uint32_t *>(vstage[buf]);
 		const uint32_t *k32 = reinterpret_cast<const uint32_t *>(kstage[buf]);
@@ -181,7 +199,7 @@ __global__ __launch_bounds__(kWorkgroup) void k_group_sum(const adac_segment_des
 					const uint64_t x64 = ty.v_sbit ? (uint64_t)(int64_t)(int32_t)x : (uint64_t)x; // ... and on to 64
 					const uint32_t k = (key[u] + (uint32_t)cur.kadd) & (uint32_t)ty.k_tmask;
 					const uint32_t bin = k < ngroups ? k : ngroups;
-					const uint32_t slot = priv ? bin * kWorkgroup + tid : bin;
+					const uint32_t slot = priv ? bin * kSets + my_set : bin;
 					if (row < cur.m) {
 						atomicAdd(&bsum[slot], (unsigned long long)x64);
 						atomicAdd(&bcnt[slot], 1u);
@@ -204,7 +222,7 @@ __global__ __launch_bounds__(kWorkgroup) void k_group_sum(const adac_segment_des
 				x = (x ^ ty.v_sbit) - ty.v_sbit; // widen by T's signedness
 				const uint64_t k = (key[u] + cur.kadd) & ty.k_tmask;
 				const uint32_t bin = k < (uint64_t)ngroups ? (uint32_t)k : ngroups;
-				const uint32_t slot = priv ? bin * kWorkgroup + tid : bin;
+				const uint32_t slot = priv ? bin * kSets + my_set : bin;
 				if (row < cur.m) {
 					atomicAdd(&bsum[slot], (unsigned long long)x); // ds_add_u64, no return: nothing waits for it
 					atomicAdd(&bcnt[slot], 1u);
@@ -212,8 +230,12 @@ __global__ __launch_bounds__(kWorkgroup) void k_group_sum(const adac_segment_des
 			}
 		}
 		if (more) {
-			if (tid < nxt.vchunks) vstage[buf ^ 1u][tid] = vq;
-			if (tid < nxt.kchunks) kstage[buf ^ 1u][tid] = kq;
+#pragma unroll
+			for (uint32_t h = 0; h < kGroupChunksPerThread; h++) {
+				const uint32_t c = tid + h * kWorkgroup;
+				if (c < nxt.vchunks) vstage[buf ^ 1u][c] = vq[h];
+				if (c < nxt.kchunks) kstage[buf ^ 1u][c] = kq[h];
+			}
 		}
 		__syncthreads();
 		cur = nxt;
@@ -222,27 +244,18 @@ __global__ __launch_bounds__(kWorkgroup) void k_group_sum(const adac_segment_des
 	}
 	// one partial per bin and workgroup
 	unsigned long long *__restrict__ mine = partial + (uint64_t)blockIdx.x * 2u * nbins;
-	if (priv) {
-		__shared__ unsigned long long wsum[kGroupPrivateBins * (kWorkgroup / 64)];
-		__shared__ unsigned long long wcnt[kGroupPrivateBins * (kWorkgroup / 64)];
-		for (uint32_t b = 0; b < nbins; b++) { // uniform
-			const uint64_t s = wave_sum((uint64_t)bsum[b * kWorkgroup + tid]);
-			const uint64_t c = wave_sum((uint64_t)bcnt[b * kWorkgroup + tid]);
-			if ((tid & 63u) == 0u) {
-				wsum[b * (kWorkgroup / 64) + (tid >> 6)] = s;
-				wcnt[b * (kWorkgroup / 64) + (tid >> 6)] = c;
+	if (priv) { // a bin's sets are added by the first wave
+		if (tid < 64u) {
+			for (uint32_t b = 0; b < nbins; b++) { // uniform
+				static_assert(kSets <= 64u, "one lane per bin set");
+				const uint64_t sv = tid < kSets ? (uint64_t)bsum[b * kSets + tid] : 0ull;
+				const uint64_t cv = tid < kSets ? (uint64_t)bcnt[b * kSets + tid] : 0ull;
+				const uint64_t ssum = wave_sum(sv), csum = wave_sum(cv);
+				if (tid == 0u) {
+					mine[2u * b] = ssum;
+					mine[2u * b + 1u] = csum;
+				}
 			}
-		}
-		__syncthreads();
-		if (tid < nbins) {
-			unsigned long long s = 0, c = 0;
-#pragma unroll
-			for (int i = 0; i < kWorkgroup / 64; i++) {
-				s += wsum[tid * (kWorkgroup / 64) + i];
-				c += wcnt[tid * (kWorkgroup / 64) + i];
-			}
-			mine[2u * tid] = s;
-			mine[2u * tid + 1u] = c;
 		}
 	} else {
 		for (uint32_t b = tid; b < nbins; b += kWorkgroup) {

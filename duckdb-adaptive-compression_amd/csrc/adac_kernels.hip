@@ -1932,9 +1932,9 @@ hipError_t launch_group_sum(hipStream_t s, uint32_t v_type_size, bool v_signed, 
 	ty.k_tmask = k_type_size >= 8 ? ~0ull : ((1ull << (8 * k_type_size)) - 1ull);
 	ty.v_tile_rows = tile_values(v_type_size);
 	ty.wide_only = g_tuning.group_sum_wide ? 1u : 0u;
-	// persistent: as many workgroups as are resident at once (three per CU: 41 KiB of LDS each), so nobody runs a
+	// persistent: as many workgroups as are resident at once (seven per CU: 21 KiB of LDS each), so nobody runs a
 	// second round on a third of the chip
-	uint64_t cap = 3ull * (uint64_t)(g_tuning.num_cus > 0 ? g_tuning.num_cus : 256);
+	uint64_t cap = 7ull * (uint64_t)(g_tuning.num_cus > 0 ? g_tuning.num_cus : 256);
 	cap = cap < kGroupMaxWorkgroups ? cap : kGroupMaxWorkgroups;
 	const uint32_t nwg = (uint32_t)(ntiles < cap ? ntiles : cap);
 	unsigned long long *partial = static_cast<unsigned long long *>(d_partial);
