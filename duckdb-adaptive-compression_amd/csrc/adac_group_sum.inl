@@ -8,8 +8,8 @@
 //   * up to kGroupPrivateBins bins (Q1: 4 - 6 groups + the overflow bin): SIXTEEN bin sets per wave, bins[b][set] with
 //     set = lane & 15 — at most four lanes collide on an LDS add whatever the keys are.  (One set per THREAD never
 //     collides but costs 24 KiB per workgroup: three workgroups per CU, and the kernel — a chain of LDS and global
-//     round trips per stage — ran at the same 0.21 ms per 60 M-row column whatever was done to its loops; with
-//     6 KiB of bins seven workgroups fit and it runs 0.085 - 0.14 ms: profiles/r02_q1_packed.json);
+//     round trips per stage — ran 0.107 - 0.22 ms per 60 M-row column; with 6 KiB of bins seven workgroups fit and
+//     it runs 0.085 - 0.14 ms: profiles/r02_q1_packed.json);
 //   * up to kGroupMaxBins bins: one bin set per workgroup, LDS atomics (collisions serialise when few keys dominate).
 // A workgroup is persistent (grid-stride over the tiles) and carries its bins across tiles; at the end it writes ONE
 // partial {sum, count} per bin, and k_group_final adds the partials — no global atomics on a handful of addresses.
