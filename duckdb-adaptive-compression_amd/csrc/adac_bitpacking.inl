@@ -173,7 +173,11 @@ __device__ __forceinline__ void bp_delta_scan(const uint32_t *lds32, uint32_t bi
 		if (base >= (int32_t)store_from && (uint32_t)(base + K) <= n) {
 			uint4 q;
 			__builtin_memcpy(&q, v[r], 16);
-			*reinterpret_cast<uint4 *>(dst + base) = q;
+			{ // non-temporal: decoded values are written once and read by somebody else (see StoreSink)
+				typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+				v4u qq = {q.x, q.y, q.z, q.w};
+				__builtin_nontemporal_store(qq, reinterpret_cast<v4u *>(dst + base));
+			}
 		} else {
 #pragma unroll
 			for (int j = 0; j < K; j++) {

@@ -74,6 +74,12 @@ __device__ __forceinline__ void store_dwords(uint32_t *p, const uint32_t *s) {
 	struct __attribute__((packed, aligned(4))) Pack {
 		uint32_t d[N];
 	};
+	if (N == 2) { // non-temporal: the packed words are written once (1.5 - 2.5 % on the whole encode)
+		typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+		v2u qq = {s[0], s[1]};
+		__builtin_nontemporal_store(qq, reinterpret_cast<v2u *>(p));
+		return;
+	}
 	Pack v;
 #pragma unroll
 	for (int i = 0; i < N; i++) v.d[i] = s[i];
@@ -114,6 +120,13 @@ __device__ __forceinline__ EncSegment<U> enc_segment(const adac_segment_desc *__
 	g.nchunks = (g.n + g.align + K - 1) / K; // <= 16 * 1024 (checked by the host)
 	g.last_chunk = g.nchunks ? g.nchunks - 1u : 0u;
 	return g;
+}
+
+// 16 bytes to global memory, non-temporal (streamed past the caches: written once, read much later)
+__device__ __forceinline__ void nt_store16(void *p, uint4 o) {
+	typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+	v4u qq = {o.x, o.y, o.z, o.w};
+	__builtin_nontemporal_store(qq, reinterpret_cast<v4u *>(p));
 }
 
 // a barrier that orders the workgroup's LDS traffic only.  __syncthreads() also drains every vector memory operation
@@ -446,7 +459,7 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 				const uint32_t g0 = c * nd - skip;
 				if (interior) {
 					if (nd == 1u) {
-						out32[g0] = s[0];
+						__builtin_nontemporal_store(s[0], out32 + g0);
 					} else {
 						store_dwords<2>(out32 + g0, s);
 					}
@@ -569,7 +582,7 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 				o.y = (uint32_t)(v0 >> 32);
 				o.z = (uint32_t)v1;
 				o.w = (uint32_t)(v1 >> 32);
-				*reinterpret_cast<uint4 *>(out + i) = o;
+				nt_store16(out + i, o);
 			} else {
 				out[i] = v0;
 			}
