@@ -1165,7 +1165,7 @@ __global__ __launch_bounds__(kWorkgroup) void k_pack(const adac_segment_desc *__
 			const int32_t pos = (int32_t)(i * w) - (int32_t)bitlo;
 			acc |= pos >= 0 ? (v << pos) : (v >> (-pos));
 		}
-		dst[q] = acc;
+		__builtin_nontemporal_store(acc, &dst[q]); // written once, read much later
 	}
 }
 
@@ -1286,7 +1286,7 @@ __global__ __launch_bounds__(kWorkgroup) void k_repack(const adac_segment_desc *
 			const int32_t pos = (int32_t)(i * w) - (int32_t)bitlo;
 			acc |= pos >= 0 ? (v << pos) : (v >> (-pos));
 		}
-		dst[q] = acc;
+		__builtin_nontemporal_store(acc, &dst[q]); // written once, read much later
 	}
 }
 
