@@ -415,7 +415,10 @@ def main():
         },
         "achieved_HBM_GBps_aggregate": comm.sum(rd + wr + meta) / (launch_ms_max * 1e-3) / 1e9,
         "parity": {"roundtrip_full_size": roundtrip_ok, "checksum_full_size": checksum_ok,
-                   "checksum_of_checksums": "%016x" % global_dev_checksum},
+                   "checksum_of_checksums": "%016x" % global_dev_checksum,
+                   "oracle_pin": "unpinned: the reference holds no tests, golden vectors or fixtures for this path and "
+                                 "its SDSL library is absent; the oracle is anchored by the known answers recorded in "
+                                 "SURVEY.md §8c (tests/golden/survey_known_answers.json)"},
     }
 
     # roofline of the dominant kernel (k_unpack<u64>) on this rank
