@@ -134,13 +134,10 @@ __global__ __launch_bounds__(kWorkgroup) void k_gather(const adac_segment_desc *
 #pragma unroll
 		for (int j = 0; j < K; j++) {
 			if ((bits >> j) & 1u) {
-#ifdef ADAC_NT_GATHER
-				__builtin_nontemporal_store(v[j], &out[slot]);
-				if (out_ids) __builtin_nontemporal_store((uint64_t)(t.elem0 + (uint32_t)base + j), &out_ids[slot]);
-#else
+				// (plain stores: these scattered 8-byte stores rely on the L2 combining them into lines — non-temporal
+				// they are 15 % slower, profiles/r02_nontemporal_stores.json)
 				out[slot] = v[j];
 				if (out_ids) out_ids[slot] = t.elem0 + (uint32_t)base + j;
-#endif
 				slot++;
 			}
 		}
