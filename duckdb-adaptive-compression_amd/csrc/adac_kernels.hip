@@ -653,6 +653,18 @@ __device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint
 				continue;
 			}
 		}
+		if (PRED && W < 4) {
+			// widths 2 and 3 (COUNT without a validity mask: see scan_run_dispatch) hold more than 32 fields per chunk,
+			// so the chunks that are not interior are counted field by field instead of through a 32-bit hit mask
+			const uint32_t have = starting < lim ? starting : lim; // 0 for lanes past the run
+			uint32_t c = 0;
+#pragma unroll
+			for (int j = 0; j < MAXV; j++) {
+				c += ((uint32_t)j < have && (field_of<W>(nrm, j) - fr.flo) <= fr.span) ? 1u : 0u;
+			}
+			acc += c;
+			continue;
+		}
 		if (PRED) {
 			// bit j of `hits` = row i0 + j satisfies the predicate: built top-down so that each field costs
 			// extract, subtract, compare and one add-with-carry (hits = 2 * hits + hit)
@@ -701,6 +713,18 @@ __device__ __forceinline__ void scan_run_dispatch(uint32_t w, const uint4 *__res
                                                   uint32_t r1, const adac_segment_desc &d, const RangePred &pred,
                                                   bool linear, const uint64_t *__restrict__ validity,
                                                   const SelOut &sel_out, uint64_t &acc) {
+	// widths 2 and 3 (u8 / u16 columns of flags and small codes): SUM and COUNT without a validity mask only — a chunk
+	// holds 64 / 43 fields, more than the 32-bit hit masks and validity windows of the other forms carry
+	if constexpr ((OP == 0 || OP == 1) && !V) {
+		if (w == 2u) {
+			scan_run_w<2, U, OP, V>(seg16, r0, r1, d, pred, linear, validity, sel_out, acc);
+			return;
+		}
+		if (w == 3u) {
+			scan_run_w<3, U, OP, V>(seg16, r0, r1, d, pred, linear, validity, sel_out, acc);
+			return;
+		}
+	}
 	switch (w) {
 #define ADAC_W(N) case N: scan_run_w<N, U, OP, V>(seg16, r0, r1, d, pred, linear, validity, sel_out, acc); break;
 		ADAC_W(4) ADAC_W(5) ADAC_W(6) ADAC_W(7) ADAC_W(8) ADAC_W(9) ADAC_W(10) ADAC_W(11) ADAC_W(12) ADAC_W(13)
@@ -795,7 +819,8 @@ __global__ __launch_bounds__(kWorkgroup, 6) void k_scan_agg(const ScanGroup *__r
 	// (unsigned T; for the predicates also 32-bit signed T, whose order is a shift of the field's)
 	const bool by_field = kind == SEG_LINEAR ||
 	                      (kind == SEG_RAW && (pred.sbit == 0 || ((OP == 1 || OP == 3) && sizeof(U) == 4)));
-	if (templated && w >= 4 && w <= 32 && (uint64_t)d.count * w < (1ull << 31) && by_field) {
+	constexpr uint32_t kMinRegisterWidth = ((OP == 0 || OP == 1) && !V) ? 2u : 4u;
+	if (templated && w >= kMinRegisterWidth && w <= 32 && (uint64_t)d.count * w < (1ull << 31) && by_field) {
 		// width-templated register path over the whole group, no LDS
 		const uint4 *seg16 = reinterpret_cast<const uint4 *>(words + d.word_off);
 		scan_run_dispatch<U, OP, V>(w, seg16, g.first, g.first + g.n, d, pred, kind == SEG_LINEAR, validity, sel_out,
