@@ -40,6 +40,17 @@ __global__ __launch_bounds__(256) void k_stream(const uint4 *__restrict__ src, u
 }
 
 // decode-shaped traffic: every 16 bytes read become 32 bytes written (w = 32 -> u64), 256 lanes wide
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ void put16(uint4 *p, uint4 v) {
+	if (NT) {
+		v4u q = {v.x, v.y, v.z, v.w};
+		__builtin_nontemporal_store(q, reinterpret_cast<v4u *>(p));
+	} else {
+		*p = v;
+	}
+}
+template <bool NT>
 __global__ __launch_bounds__(256) void k_expand(const uint4 *__restrict__ src, uint64_t nchunks, uint32_t chunks_per_wg,
                                                 uint4 *__restrict__ dst) {
 	const uint64_t lo = (uint64_t)blockIdx.x * chunks_per_wg;
@@ -48,9 +59,17 @@ __global__ __launch_bounds__(256) void k_expand(const uint4 *__restrict__ src, u
 	for (uint64_t c = lo + threadIdx.x; c < hi; c += 256) {
 		const uint4 q = src[c];
 		// lane-contiguous 32 bytes: two dwordx4 stores, like StoreSink's output chunks of two rounds
-		dst[2 * c] = make_uint4(q.x, 0u, q.y, 0u);
-		dst[2 * c + 1] = make_uint4(q.z, 0u, q.w, 0u);
+		put16<NT>(dst + 2 * c, make_uint4(q.x, 0u, q.y, 0u));
+		put16<NT>(dst + 2 * c + 1, make_uint4(q.z, 0u, q.w, 0u));
 	}
+}
+// write-only traffic (the store ceiling), plain or non-temporal
+template <bool NT>
+__global__ __launch_bounds__(256) void k_fill(uint64_t nchunks, uint32_t chunks_per_wg, uint4 *__restrict__ dst) {
+	const uint64_t lo = (uint64_t)blockIdx.x * chunks_per_wg;
+	uint64_t hi = lo + chunks_per_wg;
+	hi = hi < nchunks ? hi : nchunks;
+	for (uint64_t c = lo + threadIdx.x; c < hi; c += 256) put16<NT>(dst + c, make_uint4((uint32_t)c, 1u, 2u, 3u));
 }
 
 int main() {
@@ -90,7 +109,8 @@ int main() {
 			first = false;
 		}
 	}
-	std::printf("], \"expand_1_to_2\": [");
+	for (int nt = 0; nt < 2; nt++) {
+	std::printf("], \"%s\": [", nt ? "expand_1_to_2_nontemporal_stores" : "expand_1_to_2");
 	{
 		const uint64_t rd = 400ull << 20; // C2-like: 400 MB read, 800 MB written
 		void *d_dst = nullptr;
@@ -100,19 +120,48 @@ int main() {
 		for (uint32_t kb_per_wg : {2u, 4u, 8u, 16u, 64u}) {
 			const uint32_t cpw = kb_per_wg * 1024 / 16;
 			const unsigned grid = (unsigned)((nch + cpw - 1) / cpw);
-			for (int i = 0; i < 3; i++)
-				hipLaunchKernelGGL(k_expand, dim3(grid), dim3(256), 0, 0, (const uint4 *)d, nch, cpw, (uint4 *)d_dst);
+			auto go = [&]() {
+				if (nt) hipLaunchKernelGGL(k_expand<true>, dim3(grid), dim3(256), 0, 0, (const uint4 *)d, nch, cpw, (uint4 *)d_dst);
+				else hipLaunchKernelGGL(k_expand<false>, dim3(grid), dim3(256), 0, 0, (const uint4 *)d, nch, cpw, (uint4 *)d_dst);
+			};
+			for (int i = 0; i < 3; i++) go();
 			CK(hipDeviceSynchronize());
 			CK(hipEventRecord(e0, 0));
 			const int reps = 10;
-			for (int i = 0; i < reps; i++)
-				hipLaunchKernelGGL(k_expand, dim3(grid), dim3(256), 0, 0, (const uint4 *)d, nch, cpw, (uint4 *)d_dst);
+			for (int i = 0; i < reps; i++) go();
 			CK(hipEventRecord(e1, 0));
 			CK(hipEventSynchronize(e1));
 			float ms = 0;
 			CK(hipEventElapsedTime(&ms, e0, e1));
 			std::printf("%s{\"read_kb_per_wg\": %u, \"workgroups\": %u, \"total_GBps\": %.0f}", first ? "" : ", ", kb_per_wg,
 			            grid, 3.0 * (double)rd * reps / (ms * 1e-3) / 1e9);
+			first = false;
+		}
+		CK(hipFree(d_dst));
+	}
+	}
+	for (int nt = 0; nt < 2; nt++) { // write-only: 800 MB
+		std::printf("], \"%s\": [", nt ? "fill_nontemporal" : "fill");
+		const uint64_t wr = 800ull << 20;
+		const uint64_t nch = wr / 16;
+		first = true;
+		for (uint32_t kb_per_wg : {4u, 16u, 64u}) {
+			const uint32_t cpw = kb_per_wg * 1024 / 16;
+			const unsigned grid = (unsigned)((nch + cpw - 1) / cpw);
+			auto go = [&]() {
+				if (nt) hipLaunchKernelGGL(k_fill<true>, dim3(grid), dim3(256), 0, 0, nch, cpw, (uint4 *)d);
+				else hipLaunchKernelGGL(k_fill<false>, dim3(grid), dim3(256), 0, 0, nch, cpw, (uint4 *)d);
+			};
+			for (int i = 0; i < 3; i++) go();
+			CK(hipDeviceSynchronize());
+			CK(hipEventRecord(e0, 0));
+			const int reps = 10;
+			for (int i = 0; i < reps; i++) go();
+			CK(hipEventRecord(e1, 0));
+			CK(hipEventSynchronize(e1));
+			float ms = 0;
+			CK(hipEventElapsedTime(&ms, e0, e1));
+			std::printf("%s{\"kb_per_wg\": %u, \"GBps\": %.0f}", first ? "" : ", ", kb_per_wg, (double)wr * reps / (ms * 1e-3) / 1e9);
 			first = false;
 		}
 	}
