@@ -654,15 +654,26 @@ __device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint
 			}
 		}
 		if (PRED && W < 4) {
-			// widths 2 and 3 (COUNT without a validity mask: see scan_run_dispatch) hold more than 32 fields per chunk,
-			// so the chunks that are not interior are counted field by field instead of through a 32-bit hit mask
+			// widths 2 and 3 hold 64 / 43 fields per chunk: the hit mask is built as two 32-bit halves
 			const uint32_t have = starting < lim ? starting : lim; // 0 for lanes past the run
-			uint32_t c = 0;
+			uint32_t lo = 0, hi = 0;
 #pragma unroll
-			for (int j = 0; j < MAXV; j++) {
-				c += ((uint32_t)j < have && (field_of<W>(nrm, j) - fr.flo) <= fr.span) ? 1u : 0u;
+			for (int j = 31; j >= 0; j--) hit_shift_in(lo, field_of<W>(nrm, j) - fr.flo, fr.span);
+#pragma unroll
+			for (int j = MAXV - 1; j >= 32; j--) hit_shift_in(hi, field_of<W>(nrm, j) - fr.flo, fr.span);
+			const uint32_t n_lo = have < 32u ? have : 32u, n_hi = have > 32u ? have - 32u : 0u;
+			lo &= n_lo >= 32u ? 0xffffffffu : ((1u << n_lo) - 1u);
+			hi &= n_hi >= 32u ? 0xffffffffu : ((1u << n_hi) - 1u);
+			const uint32_t at = i0 < r1 ? i0 : r1; // keeps a lane's element range inside this run
+			if (V) { // NULL rows take no part
+				lo &= validity_window(validity, d.val_off + at, n_lo);
+				hi &= validity_window(validity, d.val_off + at + 32u, n_hi);
 			}
-			acc += c;
+			acc += (uint32_t)__popc(lo) + (uint32_t)__popc(hi);
+			if (OP == 3 && sel_out.debug < 2) {
+				sel_or(sel_out, sh0 + at, lo, n_lo);
+				if (n_hi) sel_or(sel_out, sh0 + at + 32u, hi, n_hi);
+			}
 			continue;
 		}
 		if (PRED) {
@@ -713,9 +724,9 @@ __device__ __forceinline__ void scan_run_dispatch(uint32_t w, const uint4 *__res
                                                   uint32_t r1, const adac_segment_desc &d, const RangePred &pred,
                                                   bool linear, const uint64_t *__restrict__ validity,
                                                   const SelOut &sel_out, uint64_t &acc) {
-	// widths 2 and 3 (u8 / u16 columns of flags and small codes): SUM and COUNT without a validity mask only — a chunk
-	// holds 64 / 43 fields, more than the 32-bit hit masks and validity windows of the other forms carry
-	if constexpr ((OP == 0 || OP == 1) && !V) {
+	// widths 2 and 3 (u8 / u16 columns of flags and small codes): a chunk holds 64 / 43 fields; every form but the SUM
+	// under a validity mask (one 32-bit validity window per chunk) walks them in registers
+	if constexpr (!(OP == 0 && V)) {
 		if (w == 2u) {
 			scan_run_w<2, U, OP, V>(seg16, r0, r1, d, pred, linear, validity, sel_out, acc);
 			return;
@@ -819,7 +830,7 @@ __global__ __launch_bounds__(kWorkgroup, 6) void k_scan_agg(const ScanGroup *__r
 	// (unsigned T; for the predicates also 32-bit signed T, whose order is a shift of the field's)
 	const bool by_field = kind == SEG_LINEAR ||
 	                      (kind == SEG_RAW && (pred.sbit == 0 || ((OP == 1 || OP == 3) && sizeof(U) == 4)));
-	constexpr uint32_t kMinRegisterWidth = ((OP == 0 || OP == 1) && !V) ? 2u : 4u;
+	constexpr uint32_t kMinRegisterWidth = (OP == 0 && V) ? 4u : 2u;
 	if (templated && w >= kMinRegisterWidth && w <= 32 && (uint64_t)d.count * w < (1ull << 31) && by_field) {
 		// width-templated register path over the whole group, no LDS
 		const uint4 *seg16 = reinterpret_cast<const uint4 *>(words + d.word_off);
