@@ -35,13 +35,43 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s s
 
 
 def kernel_source_sha256():
-    """Hash of the kernel sources a PMC traffic record belongs to (profiles/summarize.py writes the same hash)."""
-    import hashlib
-    h = hashlib.sha256()
-    for f in ("adac_kernels.hip", "adac_internal.h"):
-        with open(os.path.join(ROOT, PKG, "csrc", f), "rb") as fh:
-            h.update(fh.read())
-    return h.hexdigest()
+    """Hash of the device sources a PMC traffic record belongs to: the .hip, the internal header and every .inl
+    (one helper, in the package, shared with profiles/summarize.py)."""
+    return importlib.import_module(PKG).kernel_source_sha256()
+
+
+def pmc_traffic_for(kernel, rows):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json) — used ONLY when they
+    were measured on these very kernel sources and this row count; otherwise (None, reason).  The PMC passes cannot
+    run inside this process (separate rocprofv3 --pmc runs, tools/profile_round.sh)."""
+    src = {"measured_in_this_run": False, "file": "profiles/pmc_traffic.json"}
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        src.update(round=pmc.get("round"), kernel_source_sha256=pmc.get("kernel_source_sha256"))
+        rec = pmc.get("kernels", {}).get(kernel)
+        if pmc.get("kernel_source_sha256") != kernel_source_sha256():
+            src["dropped"] = "stale: kernel sources changed since the PMC passes of that round"
+        elif pmc.get("rows") != rows or rec is None:
+            src["dropped"] = "measured on a different workload (rows %s) or kernel not recorded" % pmc.get("rows")
+        else:
+            return rec, src
+    except Exception as e:  # noqa: BLE001
+        src["dropped"] = "unreadable: %s" % e
+    return None, src
+
+
+def host_cpu():
+    """(model name, logical cores of the box, cores this process may use)"""
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return model, os.cpu_count() or usable, usable
 
 
 def spawn_ranks(n):
@@ -113,7 +143,7 @@ def time_launches(ctx, fn, reps):
     return ms / reps
 
 
-def cpu_baseline(orc, col, vals, seconds, threads):
+def cpu_baseline(orc, col, vals, seconds, threads, all_threads):
     """The oracle's port of the reference scan loop (per-value read_int + min add, 2048 rows per call) on the
     host cores, over the same packed words the GPU produced; also proves at full size that the oracle decodes
     the device-packed column back to the input."""
@@ -147,6 +177,17 @@ def cpu_baseline(orc, col, vals, seconds, threads):
         total_t += t
         reps += 1
     mt_rate = rows * reps / total_t
+    # the same loop on every core this process may use ("all cores"), bounded to a third of the budget
+    all_rate = mt_rate
+    if all_threads != threads:
+        run(all_threads)
+        areps, atotal = 0, 0.0
+        while atotal < seconds / 3 and areps < 100:
+            t, rows = run(all_threads)
+            atotal += t
+            areps += 1
+        all_rate = rows * areps / atotal
+    model, box_cores, usable = host_cpu()
     # single thread on a bounded sample of segments: copy-free and faithful (whole-vector copy per call)
     k = min(len(seg_words), 96)
     t1, r1 = run(1, k)
@@ -156,6 +197,10 @@ def cpu_baseline(orc, col, vals, seconds, threads):
         "value": mt_rate, "unit": "values/s", "cores": threads, "kind": "port",
         "sample": "full column (%d rows, %d segments) x %d passes, copy-free scan loop, %d host threads, "
                   "one contiguous segment range per thread" % (n, len(seg_words), reps, threads),
+        "cpu_model": model, "host_cores": box_cores, "usable_cores": usable,
+        "all_cores": {"value": all_rate, "cores": all_threads,
+                      "note": "the same loop with one segment range per usable core (the box's whole CPU, not the "
+                              "per-GPU share)"},
         "single_thread_value": r1 / t1,
         "single_thread_faithful_copy_value": r2 / t2,
         "faithful_note": "faithful = with the reference's per-call deep copy of the segment's int_vector "
@@ -248,10 +293,14 @@ def plumbing_only(args, comm):
     total_rows = comm.sum(row_hi - row_lo)
     nseg_total = comm.sum(seg_hi - seg_lo)
     checksum = comm.sum_u64(int(vals.sum(dtype=np.uint64)))
+    # the per-GPU block of the real line: every rank's rows / segments (device = the local rank it would bind)
+    per_rank = [{"rank": int(r[0]), "device": int(r[1]), "rows": int(r[2]), "segments": int(r[3])}
+                for r in comm.gather_rows([comm.rank, comm.local_rank, row_hi - row_lo, seg_hi - seg_lo])]
     comm.barrier()
     if comm.rank == 0:
         whole = wl.zipf_column(total, np.uint64, domain=args.domain, skew=args.skew, seed=42, threads=2)
         print(json.dumps({"metric": "plumbing-only", "value": None, "n_gpus": comm.world, "data": "plumbing-only",
+                          "scaling": "strong" if args.total_rows else "weak", "per_rank": per_rank,
                           "max_elapsed": elapsed, "total_rows": total_rows, "total_segments": nseg_total,
                           "rank0_rows": row_hi - row_lo, "rank0_segments": [seg_lo, seg_hi],
                           "checksum_of_checksums": "%016x" % checksum,
@@ -385,6 +434,10 @@ def main():
     value = total_rows * args.steps / elapsed
     launch_ms = ev_ms / args.steps
     launch_ms_max = comm.max(launch_ms)
+    # per GPU (north star: "aggregate and per-GPU"): every rank's own rows / its own HIP-event launch time
+    per_rank = [{"rank": int(r[0]), "device": int(r[1]), "rows": int(r[2]), "segments": int(r[3]),
+                 "launch_ms": r[4], "values_per_s": r[2] / (r[4] * 1e-3), "hbm_GBps": r[5] / (r[4] * 1e-3) / 1e9}
+                for r in comm.gather_rows([rank, local_rank, my_rows, len(counts), launch_ms, rd + wr + meta])]
 
     result = {
         "metric": "decoded values/sec + achieved HBM GB/s, Zipf uint64 column",
@@ -395,7 +448,8 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        # --total-rows fixes the whole job (ONE column cut N ways: strong); otherwise every rank brings --rows (weak)
+        "scaling": "strong" if args.total_rows else "weak",
         "vs_baseline": None,
         "dtype": "u64",
         "data": "synthetic",
@@ -413,6 +467,9 @@ def main():
             "sharding": "the column's segment list partitioned by segment id into %d contiguous ranges, one pool per "
                         "GPU, no collective on the data path" % world,
         },
+        "per_rank": per_rank,
+        "per_gpu_values_per_s": {"min": min(r["values_per_s"] for r in per_rank),
+                                 "max": max(r["values_per_s"] for r in per_rank)},
         "achieved_HBM_GBps_aggregate": comm.sum(rd + wr + meta) / (launch_ms_max * 1e-3) / 1e9,
         "parity": {"roundtrip_full_size": roundtrip_ok, "checksum_full_size": checksum_ok,
                    "checksum_of_checksums": "%016x" % global_dev_checksum,
@@ -423,22 +480,8 @@ def main():
 
     # roofline of the dominant kernel (k_unpack<u64>) on this rank
     ach = (rd + wr + meta) / (launch_ms * 1e-3) / 1e9
-    # HBM traffic from the PMC counters cannot be collected inside this process (separate rocprofv3 --pmc passes):
-    # it is the committed figure of the last profiled run, used ONLY when it was measured on these very kernel
-    # sources and this row count; otherwise null, with the reason
-    traffic, traffic_source = None, {"measured_in_this_run": False, "file": "profiles/pmc_traffic.json"}
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    try:
-        pmc = json.load(open(pmc_path))
-        traffic_source.update(round=pmc.get("round"), kernel_source_sha256=pmc.get("kernel_source_sha256"))
-        if pmc.get("kernel_source_sha256") != kernel_source_sha256():
-            traffic_source["dropped"] = "stale: kernel sources changed since the PMC passes of that round"
-        elif pmc.get("rows") != my_rows or pmc.get("kernel") != "k_unpack<u64>":
-            traffic_source["dropped"] = "measured on a different workload (rows %s)" % pmc.get("rows")
-        else:
-            traffic = pmc.get("hbm_bytes_per_launch")
-    except Exception as e:  # noqa: BLE001
-        traffic_source["dropped"] = "unreadable: %s" % e
+    rec, traffic_source = pmc_traffic_for("k_unpack<u64>", my_rows)
+    traffic = rec["hbm_bytes"] if rec else None
     result["roofline"] = {
         "kernel": "k_unpack<u64>", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
@@ -471,6 +514,17 @@ def main():
         result["fused_scan"] = {
             "kernel": "k_scan_agg<u64,sum>", "values_per_s": my_rows / (ms_sum * 1e-3),
             "read_GBps": rd / (ms_sum * 1e-3) / 1e9, "read_frac_of_peak": rd / (ms_sum * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        }
+        # the north star's own figure — fraction of the HBM-READ roofline — is reachable only by a scan that does not
+        # materialise (a decode to u64 writes 2 bytes per byte read at w = 32): the fused SUM over the same column
+        rec_r, src_r = pmc_traffic_for("k_scan_agg<u64,sum>", my_rows)
+        result["roofline_read"] = {
+            "kernel": "k_scan_agg<u64,sum>", "bound": "hbm", "achieved": rd / (ms_sum * 1e-3) / 1e9,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rd / (ms_sum * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "traffic": rec_r["hbm_bytes"] if rec_r else None, "traffic_source": src_r,
+            "algorithmic_bytes_per_launch": rd, "launch_ms": ms_sum,
+            "note": "algorithmic bytes = the packed words of every segment (w/8 per value), nothing written but one "
+                    "64-bit sum per segment",
         }
         # filter scan with a selection-bitmap result (FilterSelection on packed bytes): value <= median
         d_bm = torch.zeros((my_rows + 63) // 64 + 1, dtype=torch.int64, device=col.d_vals.device)
@@ -540,7 +594,7 @@ def main():
             import oracle as orc
             orc.build()
             threads = max(1, min(ncpu, args.cpu_threads))
-            result["cpu_baseline"] = cpu_baseline(orc, col, vals, args.cpu_seconds, threads)
+            result["cpu_baseline"] = cpu_baseline(orc, col, vals, args.cpu_seconds, threads, ncpu)
         if not args.no_sweep:
             del col.d_out
             torch.cuda.empty_cache()

@@ -242,16 +242,6 @@ def q6_packed(adac, n=59_986_052):
     for _ in range(reps):
         q6()
     ms = ctx.timer_stop() / reps
-    # the same eleven memsets + kernels replayed as one HIP graph
-    graph = ctx.capture(q6)
-    graph.launch()
-    ctx.sync()
-    assert int(d_sum.download(np.uint64, len(counts)).sum(dtype=np.uint64)) == got
-    ctx.timer_start()
-    for _ in range(reps):
-        graph.launch()
-    ms_graph = ctx.timer_stop() / reps
-    graph.close()
     steps = {}
     for name, fn in (("select_shipdate", lambda: enc["l_shipdate"][0].scan_select_between(enc["l_shipdate"][1], 8766, 9130, bm[0], d_cnt)),
                      ("select_discount_masked", lambda: enc["l_discount"][0].scan_select_between(enc["l_discount"][1], 5, 7, bm[1], d_cnt, bm[0])),
@@ -279,7 +269,7 @@ def q6_packed(adac, n=59_986_052):
             lay.unpack(w, d_out)
     ms_dec = ctx.timer_stop() / reps
     out = {"rows": n, "selected_rows": int(m.sum()), "widths": {k: v[2] for k, v in enc.items()},
-           "packed_bytes": packed_bytes, "q6_on_packed_ms": ms, "q6_as_hip_graph_ms": ms_graph, "q6_rows_per_s": n / (ms * 1e-3),
+           "packed_bytes": packed_bytes, "q6_on_packed_ms": ms, "q6_rows_per_s": n / (ms * 1e-3),
            "q6_packed_read_GBps": packed_bytes / (ms * 1e-3) / 1e9,
            "decode_four_columns_ms": ms_dec,
            "decode_four_columns_total_GBps": (packed_bytes + 4 * n * 4) / (ms_dec * 1e-3) / 1e9, "q6_ms_by_scan_tiles_per_wg": by_group, "step_ms": steps,

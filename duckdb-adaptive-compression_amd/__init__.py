@@ -66,6 +66,20 @@ def numpy_dtype(ptype):
     return _TYPE2NP[ptype]
 
 
+def kernel_source_sha256():
+    """Hash of EVERY device source of libadacodec (adac_kernels.hip, adac_internal.h and each csrc/*.inl it includes):
+    a PMC traffic record belongs to the kernels it was measured on, and bench.py attaches one only while this hash
+    equals the record's (profiles/summarize.py writes the same hash)."""
+    import hashlib
+    csrc = os.path.join(_HERE, "csrc")
+    h = hashlib.sha256()
+    for f in ["adac_kernels.hip", "adac_internal.h"] + sorted(x for x in os.listdir(csrc) if x.endswith(".inl")):
+        h.update(f.encode())
+        with open(os.path.join(csrc, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def build(force=False):
     """Compile libadacodec.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))]
@@ -146,10 +160,6 @@ SIGNATURES = {
     "adac_event_wait": (_int, [_vp]),
     "adac_event_done": (_int, [_vp]),
     "adac_event_destroy": (None, [_vp]),
-    "adac_capture_begin": (_int, [_vp]),
-    "adac_capture_end": (_int, [_vp, C.POINTER(_vp)]),
-    "adac_graph_launch": (_int, [_vp]),
-    "adac_graph_destroy": (None, [_vp]),
     "adac_scan_sum": (_int, [_vp, _vp, _vp]),
     "adac_scan_group_sum": (_int, [_vp, _vp, _vp, _vp, _u32, _vp, _vp]),
     "adac_scan_count_eq": (_int, [_vp, _vp, _u64, _vp]),
@@ -372,17 +382,6 @@ class Context:
         arr = np.ascontiguousarray(arr)
         return DeviceBuffer(self, max(arr.nbytes, 16)).upload(arr)
 
-    def capture(self, fn):
-        """Run fn() (enqueue calls on this context only, after an eager warm-up) under HIP-graph capture."""
-        _check(lib().adac_capture_begin(self._h), "adac_capture_begin")
-        try:
-            fn()
-        finally:
-            g = _vp()
-            st = lib().adac_capture_end(self._h, C.byref(g))
-        _check(st, "adac_capture_end")
-        return Graph(g)
-
     def timer_start(self):
         _check(lib().adac_timer_start(self._h), "adac_timer_start")
 
@@ -424,27 +423,6 @@ class Event:
     def close(self):
         if getattr(self, "_h", None):
             lib().adac_event_destroy(self._h)
-            self._h = None
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:  # pragma: no cover
-            pass
-
-
-class Graph:
-    """A captured sequence of codec calls (adac_graph): launch() replays it on the context's stream."""
-
-    def __init__(self, handle):
-        self._h = handle
-
-    def launch(self):
-        _check(lib().adac_graph_launch(self._h), "adac_graph_launch")
-
-    def close(self):
-        if self._h:
-            lib().adac_graph_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -73,6 +73,12 @@ struct adac_layout {
 	uint64_t ngroups = 0;
 	int groups_tiles = 0;
 	bool groups_dirty = true;
+	// the groups of segments at widths 2 and 3, which a scan kernel of their own takes (k_scan_agg<.., NARROW>): the
+	// expansion lists them on the device and their number comes back through a page-locked word; the first scan after
+	// an expansion waits for that copy (it would wait for the same stream work in its own launch anyway)
+	uint32_t *d_narrow_idx = nullptr, *d_narrow_count = nullptr, *h_narrow_count = nullptr;
+	hipEvent_t narrow_ev = nullptr;
+	bool narrow_pending = false;
 	// scratch of adac_unpack_selected: selected rows per tile, their exclusive prefix, block totals + grand total
 	uint32_t *d_tile_cnt = nullptr;
 	uint64_t *d_tile_off = nullptr;
@@ -335,7 +341,7 @@ extern "C" int adac_set_tuning(const char *name, int value) {
 	else if (n == "templated_scan") adac::g_tuning.templated_scan = value;
 	else if (n == "scan_tiles_per_wg" && value >= 0) adac::g_tuning.scan_tiles_per_wg = value; // 0 = by type
 	else if (n == "blocks_per_cu" && value > 0) adac::g_tuning.blocks_per_cu = value;
-	else if (n == "num_cus" && value > 0) adac::g_tuning.num_cus = value;
+	else if (n == "num_cus" && value >= 0) adac::g_tuning.num_cus = value;
 	else return 1;
 	return 0;
 }
@@ -474,64 +480,6 @@ extern "C" adac_status adac_timer_stop(adac_ctx *c, float *ms) {
 	return ADAC_OK;
 }
 
-// Capture of a sequence of enqueue calls into a HIP graph: short pipelines (a multi-column filter + aggregate is
-// a dozen memsets and kernels of 20-50 us each) replay with one launch instead of one per node.
-struct adac_graph {
-	adac_ctx *ctx = nullptr;
-	hipGraph_t graph = nullptr;
-	hipGraphExec_t exec = nullptr;
-};
-
-extern "C" adac_status adac_capture_begin(adac_ctx *c) {
-	if (!c) return ADAC_ERR_INVALID_ARGUMENT;
-	ADAC_HIP(hipSetDevice(c->device));
-	ADAC_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-	return ADAC_OK;
-}
-
-extern "C" adac_status adac_capture_end(adac_ctx *c, adac_graph **out) {
-	if (!c || !out) return ADAC_ERR_INVALID_ARGUMENT;
-	*out = nullptr;
-	ADAC_HIP(hipSetDevice(c->device));
-	hipGraph_t g = nullptr;
-	ADAC_HIP(hipStreamEndCapture(c->stream, &g));
-	hipGraphExec_t exec = nullptr;
-	hipError_t e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
-	if (e != hipSuccess) {
-		(void)hipGraphDestroy(g);
-		return fail_hip(e, "hipGraphInstantiate");
-	}
-	adac_graph *h = new (std::nothrow) adac_graph();
-	if (!h) {
-		(void)hipGraphExecDestroy(exec);
-		(void)hipGraphDestroy(g);
-		return ADAC_ERR_OUT_OF_MEMORY;
-	}
-	h->ctx = c;
-	ctx_retain(c);
-	h->graph = g;
-	h->exec = exec;
-	*out = h;
-	return ADAC_OK;
-}
-
-extern "C" adac_status adac_graph_launch(adac_graph *g) {
-	if (!g) return ADAC_ERR_INVALID_ARGUMENT;
-	ADAC_HIP(hipSetDevice(g->ctx->device));
-	ADAC_HIP(hipGraphLaunch(g->exec, g->ctx->stream));
-	return ADAC_OK;
-}
-
-extern "C" void adac_graph_destroy(adac_graph *g) {
-	if (!g) return;
-	(void)hipSetDevice(g->ctx->device);
-	if (g->exec) (void)hipGraphExecDestroy(g->exec);
-	if (g->graph) (void)hipGraphDestroy(g->graph);
-	adac_ctx *c = g->ctx;
-	delete g;
-	ctx_release(c);
-}
-
 // ------------------------------------------------------------------------------------------------
 // layout
 // ------------------------------------------------------------------------------------------------
@@ -617,6 +565,10 @@ extern "C" void adac_layout_destroy(adac_layout *l) {
 	if (l->d_block_tot) (void)hipFree(l->d_block_tot);
 	if (l->d_group_refs) (void)hipFree(l->d_group_refs);
 	if (l->d_groups) (void)hipFree(l->d_groups);
+	if (l->d_narrow_idx) (void)hipFree(l->d_narrow_idx);
+	if (l->d_narrow_count) (void)hipFree(l->d_narrow_count);
+	if (l->h_narrow_count) (void)hipHostFree(l->h_narrow_count);
+	if (l->narrow_ev) (void)hipEventDestroy(l->narrow_ev);
 	if (l->d_scan_state) (void)hipFree(l->d_scan_state);
 	if (l->d_group_partial) (void)hipFree(l->d_group_partial);
 	if (l->d_sel_edges) (void)hipFree(l->d_sel_edges);
@@ -669,12 +621,32 @@ static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Descriptors changed (plan / set_descs): re-expand the scans' work-item records in stream order right away when
 // the table exists, so that a captured graph replayed after a re-encode reads current records; otherwise the
 // next scan builds the table.
+static adac_status expand_groups(adac_layout *l) {
+	ADAC_HIP(adac::launch_expand_groups(l->ctx->stream, l->d_descs, l->d_group_refs, l->ngroups, l->d_groups,
+	                                    l->d_narrow_idx, l->d_narrow_count));
+	ADAC_HIP(hipMemcpyAsync(l->h_narrow_count, l->d_narrow_count, sizeof(uint32_t), hipMemcpyDeviceToHost,
+	                        l->ctx->stream));
+	ADAC_HIP(hipEventRecord(l->narrow_ev, l->ctx->stream));
+	l->narrow_pending = true;
+	l->groups_dirty = false;
+	return ADAC_OK;
+}
+
 static adac_status descs_changed(adac_layout *l) {
 	l->groups_dirty = true;
-	if (l->d_groups && l->groups_tiles > 0) {
-		ADAC_HIP(adac::launch_expand_groups(l->ctx->stream, l->d_descs, l->d_group_refs, l->ngroups, l->d_groups));
-		l->groups_dirty = false;
+	if (l->d_groups && l->groups_tiles > 0) return expand_groups(l);
+	return ADAC_OK;
+}
+
+// the scans' view of the work items; waits for the narrow-group count of the last expansion if it is still on its way
+static adac_status scan_group_list(adac_layout *l, adac::ScanGroupList *gl) {
+	adac_status gst = ensure_scan_groups(l);
+	if (gst != ADAC_OK) return gst;
+	if (l->narrow_pending) {
+		ADAC_HIP(hipEventSynchronize(l->narrow_ev));
+		l->narrow_pending = false;
 	}
+	*gl = adac::ScanGroupList {l->d_groups, l->ngroups, l->d_narrow_idx, *l->h_narrow_count};
 	return ADAC_OK;
 }
 
@@ -952,11 +924,20 @@ static adac_status ensure_scan_groups(adac_layout *l) {
 		if (refs.size() >= 0x7fffffffull) return ADAC_ERR_INVALID_ARGUMENT;
 		if (l->d_group_refs) (void)hipFree(l->d_group_refs);
 		if (l->d_groups) (void)hipFree(l->d_groups);
+		if (l->d_narrow_idx) (void)hipFree(l->d_narrow_idx);
 		l->d_group_refs = nullptr;
 		l->d_groups = nullptr;
+		l->d_narrow_idx = nullptr;
 		l->ngroups = refs.size();
 		ADAC_HIP(hipMalloc((void **)&l->d_group_refs, (refs.size() ? refs.size() : 1) * sizeof(adac::ScanGroupRef)));
 		ADAC_HIP(hipMalloc((void **)&l->d_groups, (refs.size() ? refs.size() : 1) * sizeof(adac::ScanGroup)));
+		ADAC_HIP(hipMalloc((void **)&l->d_narrow_idx, (refs.size() ? refs.size() : 1) * sizeof(uint32_t)));
+		if (!l->d_narrow_count) {
+			ADAC_HIP(hipMalloc((void **)&l->d_narrow_count, sizeof(uint32_t)));
+			ADAC_HIP(hipHostMalloc((void **)&l->h_narrow_count, sizeof(uint32_t), hipHostMallocDefault));
+			ADAC_HIP(hipEventCreateWithFlags(&l->narrow_ev, hipEventDisableTiming));
+			*l->h_narrow_count = 0;
+		}
 		if (!refs.empty()) {
 			ADAC_HIP(hipMemcpyAsync(l->d_group_refs, refs.data(), refs.size() * sizeof(adac::ScanGroupRef),
 			                        hipMemcpyHostToDevice, l->ctx->stream));
@@ -965,10 +946,7 @@ static adac_status ensure_scan_groups(adac_layout *l) {
 		l->groups_tiles = per;
 		l->groups_dirty = true;
 	}
-	if (l->groups_dirty) {
-		ADAC_HIP(adac::launch_expand_groups(l->ctx->stream, l->d_descs, l->d_group_refs, l->ngroups, l->d_groups));
-		l->groups_dirty = false;
-	}
+	if (l->groups_dirty) return expand_groups(l);
 	return ADAC_OK;
 }
 
@@ -985,10 +963,10 @@ extern "C" adac_status adac_scan_sum_valid(adac_layout *l, const uint64_t *d_wor
 	ADAC_HIP(hipSetDevice(l->ctx->device));
 	if (l->nseg) ADAC_HIP(hipMemsetAsync(d_sums, 0, l->nseg * sizeof(uint64_t), l->ctx->stream));
 	const uint64_t sbit = l->is_signed ? (1ull << (8 * l->type_size - 1)) : 0ull;
-	adac_status gst = ensure_scan_groups(l);
+	adac::ScanGroupList gl;
+	adac_status gst = scan_group_list(l, &gl);
 	if (gst != ADAC_OK) return gst;
-	ADAC_HIP(adac::launch_scan_sum(l->ctx->stream, l->type_size, l->d_groups, l->ngroups, d_words, d_validity, sbit,
-	                               d_sums));
+	ADAC_HIP(adac::launch_scan_sum(l->ctx->stream, l->type_size, gl, d_words, d_validity, sbit, d_sums));
 	return ADAC_OK;
 }
 
@@ -1040,7 +1018,8 @@ static adac_status scan_range(adac_layout *l, const uint64_t *d_words, const uin
 		ADAC_HIP(hipMemsetAsync(d_bitmap, 0, ((l->value_span + 63) / 64) * sizeof(uint64_t), l->ctx->stream));
 	}
 	if (bhi < blo) return ADAC_OK; // empty range: all counts (and bits) stay zero
-	adac_status gst = ensure_scan_groups(l);
+	adac::ScanGroupList gl;
+	adac_status gst = scan_group_list(l, &gl);
 	if (gst != ADAC_OK) return gst;
 	if (edges_only && l->sel_edges_groups < l->ngroups) {
 		if (l->d_sel_edges) ADAC_HIP(hipFree(l->d_sel_edges));
@@ -1049,8 +1028,8 @@ static adac_status scan_range(adac_layout *l, const uint64_t *d_words, const uin
 		ADAC_HIP(hipMalloc(&l->d_sel_edges, adac::sel_edge_bytes(l->ngroups)));
 		l->sel_edges_groups = l->ngroups;
 	}
-	ADAC_HIP(adac::launch_scan_count_range(l->ctx->stream, l->type_size, l->d_groups, l->ngroups, d_words, d_validity,
-	                                       blo, bhi - blo, sbit, d_counts, want_bitmap ? d_bitmap : nullptr,
+	ADAC_HIP(adac::launch_scan_count_range(l->ctx->stream, l->type_size, gl, d_words, d_validity, blo, bhi - blo, sbit,
+	                                       d_counts, want_bitmap ? d_bitmap : nullptr,
 	                                       edges_only ? l->d_sel_edges : nullptr));
 	if (edges_only) {
 		const uint64_t words32 = (l->value_span + 31) / 32; // the odd half of the last 64-bit word, if there is one

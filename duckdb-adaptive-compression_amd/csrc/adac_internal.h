@@ -79,7 +79,7 @@ struct Tuning {
 	int scan_probe = 0;         // diagnostic: fused-scan loop + loads only (no field walk)
 	int templated_scan = 1;     // width-templated register path of the fused scans for 4 <= w <= 32
 	int scan_tiles_per_wg = 0; // tiles per fused-scan workgroup; 0 = by type (12 tiles of u64, 6 of u32, 8 of u16, 4 of u8)
-	int num_cus = 256;      // MI355X: 8 XCDs x 32 CUs
+	int num_cus = 0;        // 0 = the device's own count (256 on a whole MI355X: 8 XCDs x 32 CUs); > 0 overrides
 	int blocks_per_cu = 8;  // 256-thread workgroups resident per CU (2048 threads, <= 16.5 KiB LDS each)
 };
 extern Tuning g_tuning;
@@ -132,20 +132,28 @@ hipError_t launch_analyze_packed_g(hipStream_t s, uint32_t type_size, bool sign_
 hipError_t launch_repack_g(hipStream_t s, uint32_t type_size, uint64_t null_bits, const ScanGroup *d_src_groups,
                            uint64_t ngroups, const adac_segment_desc *d_dst_descs, const uint64_t *d_src_words,
                            const uint64_t *d_validity, uint64_t *d_dst_words);
+// The fused scans' work items as the launchers see them: every group, and the indices of those at widths 2 and 3,
+// which a kernel of their own scans (n_narrow is read back once per expansion).
+struct ScanGroupList {
+	const ScanGroup *d_groups;
+	uint64_t ngroups;
+	const uint32_t *d_narrow_idx;
+	uint32_t n_narrow;
+};
 hipError_t launch_expand_groups(hipStream_t s, const adac_segment_desc *d_descs, const ScanGroupRef *d_refs,
-                                uint64_t ngroups, ScanGroup *d_groups);
+                                uint64_t ngroups, ScanGroup *d_groups, uint32_t *d_narrow_idx, uint32_t *d_narrow_count);
 hipError_t launch_gather_selected(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs,
                                   const TileRef *d_tiles, uint64_t ntiles, const uint64_t *d_words,
                                   const uint64_t *d_bitmap, uint32_t *d_tile_cnt, uint64_t *d_tile_off,
                                   uint64_t *d_block_tot, void *d_out, uint64_t *d_out_ids, uint64_t *d_total);
-hipError_t launch_scan_sum(hipStream_t s, uint32_t type_size, const ScanGroup *d_groups, uint64_t ngroups,
-                           const uint64_t *d_words, const uint64_t *d_validity, uint64_t sbit, uint64_t *d_sums);
+hipError_t launch_scan_sum(hipStream_t s, uint32_t type_size, const ScanGroupList &gl, const uint64_t *d_words,
+                           const uint64_t *d_validity, uint64_t sbit, uint64_t *d_sums);
 uint64_t sel_edge_bytes(uint64_t ngroups);
 hipError_t launch_sel_merge_edges(hipStream_t s, const void *d_edges, uint64_t ngroups, uint64_t *d_bitmap,
                                   uint64_t tail_word);
-hipError_t launch_scan_count_range(hipStream_t s, uint32_t type_size, const ScanGroup *d_groups, uint64_t ngroups,
-                                   const uint64_t *d_words, const uint64_t *d_validity, uint64_t blo, uint64_t bspan,
-                                   uint64_t sbit, uint64_t *d_counts, uint64_t *d_bitmap, void *d_edges);
+hipError_t launch_scan_count_range(hipStream_t s, uint32_t type_size, const ScanGroupList &gl, const uint64_t *d_words,
+                                   const uint64_t *d_validity, uint64_t blo, uint64_t bspan, uint64_t sbit,
+                                   uint64_t *d_counts, uint64_t *d_bitmap, void *d_edges);
 
 // Persistent block images (adac_block_image.inl): one segment's packed words <-> its image in a block buffer.
 struct BlockJob {

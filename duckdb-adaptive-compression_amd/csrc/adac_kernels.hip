@@ -18,6 +18,7 @@
 //   k_fetch         SuccinctFetchRow (intended)         src/storage/compression/succinct.cpp:244-260
 //   bit layout      sdsl::bits::read_int / write_int    third_party/sdsl/include/sdsl/bits.hpp:456-529
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include <type_traits>
@@ -68,6 +69,27 @@ __device__ __forceinline__ uint64_t wave_sum(uint64_t v) {
 	return v;
 }
 
+// A descriptor at a wave-uniform address through the scalar unit: read as eight dwords (s_load_dwordx8) and taken
+// apart with scalar shifts.  Read field by field, the byte-sized members (width, flags) come through VECTOR loads —
+// gfx9 has no sub-dword scalar load — each behind its own s_waitcnt: one more memory round trip at the start of every
+// workgroup, before the first data load can be issued.
+__device__ __forceinline__ adac_segment_desc load_desc(const adac_segment_desc *__restrict__ p) {
+	static_assert(sizeof(adac_segment_desc) == 32, "record layout");
+	const uint32_t *__restrict__ q = reinterpret_cast<const uint32_t *>(p);
+	uint32_t w[8];
+#pragma unroll
+	for (int i = 0; i < 8; i++) w[i] = q[i];
+	adac_segment_desc d;
+	d.word_off = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+	d.val_off = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+	d.min = (uint64_t)w[4] | ((uint64_t)w[5] << 32);
+	d.count = w[6];
+	d.width = (uint8_t)(w[7] & 0xffu);
+	d.flags = (uint8_t)((w[7] >> 8) & 0xffu);
+	d.reserved = (uint16_t)(w[7] >> 16);
+	return d;
+}
+
 // A tile resolved to its segment.
 struct TileCtx {
 	adac_segment_desc d;
@@ -84,7 +106,7 @@ __device__ __forceinline__ TileCtx resolve_tile(const adac_segment_desc *__restr
 	const TileRef r = tiles[blockIdx.x];
 	t.seg = r.seg;
 	t.first = r.first;
-	t.d = descs[r.seg];
+	t.d = load_desc(descs + r.seg);
 	const uint32_t left = t.d.count - r.first;
 	t.n = left < (uint32_t)TILE ? left : (uint32_t)TILE;
 	t.elem0 = t.d.val_off + r.first;
@@ -301,7 +323,7 @@ __global__ __launch_bounds__(kWorkgroup) void k_unpack(const adac_segment_desc *
 	uint32_t first, n;
 	uint64_t elem0;
 	if (RANGE) {
-		d = descs[range.seg];
+		d = load_desc(descs + range.seg);
 		const uint32_t done = blockIdx.x * (uint32_t)TILE;
 		first = range.start + done;
 		const uint32_t left = range.count - done;
@@ -406,6 +428,24 @@ __device__ __forceinline__ uint32_t field_of(const uint32_t (&nrm)[5], int j) {
 	const int pos = j * W, d = pos >> 5, sh = pos & 31;
 	if (sh + W <= 32) return (nrm[d] >> sh) & mask;
 	return __builtin_amdgcn_alignbit(nrm[d + 1], nrm[d], sh) & mask;
+}
+
+__device__ __forceinline__ bool scan_width_is_narrow(uint32_t w) { return w == 2u || w == 3u; }
+
+// A workgroup's 64-byte work item through the scalar unit (see load_desc; measured: the vector loads of width / flags
+// cost 3 - 5 % of a fused scan once the narrow-width test made width the first field needed,
+// profiles/r03_scan_split_ab.json).
+__device__ __forceinline__ ScanGroup load_scan_group(const ScanGroup *__restrict__ groups, uint32_t gi) {
+	static_assert(sizeof(ScanGroup) == 64 && offsetof(ScanGroup, seg) == 32, "record layout");
+	ScanGroup g;
+	g.d = load_desc(&groups[gi].d);
+	const uint32_t *__restrict__ p = reinterpret_cast<const uint32_t *>(groups + gi);
+	g.seg = p[8];
+	g.first = p[9];
+	g.n = p[10];
+#pragma unroll
+	for (int i = 0; i < 5; i++) g.pad[i] = 0;
+	return g;
 }
 
 // A bitmap word two scan groups share: each group leaves its bits in a record of its own, k_sel_merge_edges ORs the
@@ -719,37 +759,39 @@ __device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint
 	if (OP == 1 && !V && (threadIdx.x & 63u) == 0u) acc += wave_count;
 }
 
-template <typename U, int OP, bool V>
+// The widths are dealt to TWO kernels: widths 2 and 3 (u8 / u16 columns of flags and small codes; a chunk holds 64 / 43
+// fields, walked in registers by every form but the SUM under a validity mask) live in k_scan_agg<.., NARROW = true>,
+// which only the scan groups of such segments run.  Inlined into the common kernel their unrolled bodies took
+// k_scan_agg<u64, sum> from 42 to 74 VGPRs (occupancy 8 -> 6 waves per SIMD) and cost every width 8 .. 32 about 10 %
+// (profiles/r02i vs r02k); tests/test_kernel_budget.py now holds the register budget of the common kernel.
+template <typename U, int OP, bool V, bool NARROW>
 __device__ __forceinline__ void scan_run_dispatch(uint32_t w, const uint4 *__restrict__ seg16, uint32_t r0,
                                                   uint32_t r1, const adac_segment_desc &d, const RangePred &pred,
                                                   bool linear, const uint64_t *__restrict__ validity,
                                                   const SelOut &sel_out, uint64_t &acc) {
-	// widths 2 and 3 (u8 / u16 columns of flags and small codes): a chunk holds 64 / 43 fields; every form but the SUM
-	// under a validity mask (one 32-bit validity window per chunk) walks them in registers
-	if constexpr (!(OP == 0 && V)) {
+	if constexpr (NARROW) {
 		if (w == 2u) {
 			scan_run_w<2, U, OP, V>(seg16, r0, r1, d, pred, linear, validity, sel_out, acc);
-			return;
-		}
-		if (w == 3u) {
+		} else if (w == 3u) {
 			scan_run_w<3, U, OP, V>(seg16, r0, r1, d, pred, linear, validity, sel_out, acc);
-			return;
 		}
-	}
-	switch (w) {
+	} else {
+		switch (w) {
 #define ADAC_W(N) case N: scan_run_w<N, U, OP, V>(seg16, r0, r1, d, pred, linear, validity, sel_out, acc); break;
-		ADAC_W(4) ADAC_W(5) ADAC_W(6) ADAC_W(7) ADAC_W(8) ADAC_W(9) ADAC_W(10) ADAC_W(11) ADAC_W(12) ADAC_W(13)
-		ADAC_W(14) ADAC_W(15) ADAC_W(16) ADAC_W(17) ADAC_W(18) ADAC_W(19) ADAC_W(20) ADAC_W(21) ADAC_W(22)
-		ADAC_W(23) ADAC_W(24) ADAC_W(25) ADAC_W(26) ADAC_W(27) ADAC_W(28) ADAC_W(29) ADAC_W(30) ADAC_W(31) ADAC_W(32)
+			ADAC_W(4) ADAC_W(5) ADAC_W(6) ADAC_W(7) ADAC_W(8) ADAC_W(9) ADAC_W(10) ADAC_W(11) ADAC_W(12) ADAC_W(13)
+			ADAC_W(14) ADAC_W(15) ADAC_W(16) ADAC_W(17) ADAC_W(18) ADAC_W(19) ADAC_W(20) ADAC_W(21) ADAC_W(22)
+			ADAC_W(23) ADAC_W(24) ADAC_W(25) ADAC_W(26) ADAC_W(27) ADAC_W(28) ADAC_W(29) ADAC_W(30) ADAC_W(31) ADAC_W(32)
 #undef ADAC_W
-	default: break;
+		default: break;
+		}
 	}
 }
 
 // Expansion of the scans' work items: one thread per group copies its segment's CURRENT descriptor next to the
 // group's row range, so the scan kernel reads one 64-byte record (a single hop) before it can issue data loads.
 __global__ void k_expand_groups(const adac_segment_desc *__restrict__ descs, const ScanGroupRef *__restrict__ refs,
-                                uint64_t ngroups, ScanGroup *__restrict__ groups) {
+                                uint64_t ngroups, ScanGroup *__restrict__ groups, uint32_t *__restrict__ narrow_idx,
+                                uint32_t *__restrict__ narrow_count) {
 	const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (g >= ngroups) return;
 	const ScanGroupRef r = refs[g];
@@ -761,6 +803,9 @@ __global__ void k_expand_groups(const adac_segment_desc *__restrict__ descs, con
 #pragma unroll
 	for (int i = 0; i < 5; i++) out.pad[i] = 0;
 	groups[g] = out;
+	// the groups of segments at widths 2 and 3 are also listed for the narrow scan kernel (order of arrival: the list
+	// only says who runs, every result is an exact integer)
+	if (scan_width_is_narrow(out.d.width)) narrow_idx[atomicAdd(narrow_count, 1u)] = (uint32_t)g;
 }
 
 // After a selection scan over a DENSE value space (segments back to back): the words two or more groups share.  The
@@ -797,12 +842,15 @@ __global__ void k_sel_merge_edges(const SelEdge *__restrict__ edges, uint64_t nr
 
 // OP 0: SUM, 1: COUNT(lo <= v <= hi), 2: load-only probe, 3: COUNT + selection bitmap; V: validity mask given.
 // One workgroup per ScanGroup: up to scan_tiles_per_wg consecutive tiles of ONE segment.
-template <typename U, int OP, bool V>
-__global__ __launch_bounds__(kWorkgroup, 6) void k_scan_agg(const ScanGroup *__restrict__ groups, int templated,
-                                                            const uint64_t *__restrict__ words, RangePred pred,
-                                                            const uint64_t *__restrict__ validity,
-                                                            uint64_t *__restrict__ result, uint32_t *__restrict__ bitmap32,
-                                                            SelEdge *__restrict__ edges) {
+// NARROW: the kernel of the groups at widths 2 and 3 (listed in narrow_idx by k_expand_groups); the common kernel
+// leaves those groups alone.  The SUM under a validity mask has no narrow form (its widths 2 and 3 take the LDS path).
+template <int OP, bool V> constexpr bool kScanHasNarrowKernel = !(OP == 0 && V) && OP != 2;
+
+template <typename U, int OP, bool V, bool NARROW>
+__global__ __launch_bounds__(kWorkgroup, NARROW ? 4 : 6) void k_scan_agg(
+    const ScanGroup *__restrict__ groups, const uint32_t *__restrict__ narrow_idx, int templated,
+    const uint64_t *__restrict__ words, RangePred pred, const uint64_t *__restrict__ validity,
+    uint64_t *__restrict__ result, uint32_t *__restrict__ bitmap32, SelEdge *__restrict__ edges) {
 	// LDS: the packed image of one stage of the fallback path (the register path uses none) and, for the selection
 	// scan, the bitmap image of the group.  The selection scan halves the stage so that both fit 16.4 KiB: at
 	// 24.6 KiB only six workgroups fit a CU instead of eight, and these kernels are bound by the bytes a CU keeps
@@ -812,9 +860,11 @@ __global__ __launch_bounds__(kWorkgroup, 6) void k_scan_agg(const ScanGroup *__r
 	__shared__ uint4 lds[kStageBytes / 16 + 2];
 	__shared__ uint32_t sel_img[OP == 3 ? kSelImageWords : 1];
 	const uint32_t *lds32 = reinterpret_cast<const uint32_t *>(lds);
-	const ScanGroup g = groups[blockIdx.x];
+	const uint32_t gi = NARROW ? narrow_idx[blockIdx.x] : blockIdx.x;
+	const ScanGroup g = load_scan_group(groups, gi);
 	const adac_segment_desc &d = g.d;
-	SelOut sel_out {sel_img, bitmap32, 0u, templated >> 1, edges ? edges + 2u * (uint64_t)blockIdx.x : nullptr};
+	if (!NARROW && kScanHasNarrowKernel<OP, V> && scan_width_is_narrow(d.width)) return; // the narrow kernel's group
+	SelOut sel_out {sel_img, bitmap32, 0u, templated >> 1, edges ? edges + 2u * (uint64_t)gi : nullptr};
 	templated &= 1;
 	const uint32_t sel_p0 = (uint32_t)(d.val_off & 31u) + g.first; // the group's positions [sel_p0, sel_p0 + n)
 	if (OP == 3) {
@@ -830,11 +880,11 @@ __global__ __launch_bounds__(kWorkgroup, 6) void k_scan_agg(const ScanGroup *__r
 	// (unsigned T; for the predicates also 32-bit signed T, whose order is a shift of the field's)
 	const bool by_field = kind == SEG_LINEAR ||
 	                      (kind == SEG_RAW && (pred.sbit == 0 || ((OP == 1 || OP == 3) && sizeof(U) == 4)));
-	constexpr uint32_t kMinRegisterWidth = (OP == 0 && V) ? 4u : 2u;
+	constexpr uint32_t kMinRegisterWidth = kScanHasNarrowKernel<OP, V> ? 2u : 4u;
 	if (templated && w >= kMinRegisterWidth && w <= 32 && (uint64_t)d.count * w < (1ull << 31) && by_field) {
 		// width-templated register path over the whole group, no LDS
 		const uint4 *seg16 = reinterpret_cast<const uint4 *>(words + d.word_off);
-		scan_run_dispatch<U, OP, V>(w, seg16, g.first, g.first + g.n, d, pred, kind == SEG_LINEAR, validity, sel_out,
+		scan_run_dispatch<U, OP, V, NARROW>(w, seg16, g.first, g.first + g.n, d, pred, kind == SEG_LINEAR, validity, sel_out,
 		                            acc);
 	} else {
 		// the group in stages of as many whole decode rounds as fit the image (a round of 64-bit fields is 4 KiB)
@@ -919,7 +969,7 @@ __device__ __forceinline__ TileJob make_job(const adac_segment_desc *__restrict_
                                             const TileRef *__restrict__ tiles, uint32_t t,
                                             const uint64_t *__restrict__ words) {
 	const TileRef r = tiles[t];
-	const adac_segment_desc d = descs[r.seg];
+	const adac_segment_desc d = load_desc(descs + r.seg);
 	TileJob j;
 	j.seg = r.seg;
 	const uint32_t left = d.count - r.first;
@@ -1027,11 +1077,17 @@ __global__ __launch_bounds__(kWorkgroup) void k_analyze(const adac_segment_desc 
 	constexpr int TILE = kTileBytes / (int)sizeof(U);
 	constexpr int K = 16 / (int)sizeof(U);
 	using S = typename std::make_signed<U>::type;
-	__shared__ uint64_t pmin[kWorkgroup / 64], pmax[kWorkgroup / 64];
+	// The 1-, 2- and 4-byte types reduce in 32 bits, on the bit PATTERN of T: sign extension to 64 bits is monotone in
+	// the unsigned order of the pattern (0x7f < 0x80 and 0x7f < 0xff...80), so min / max commute with the widening of
+	// rule APPEND (succinct.cpp:286-287) and the result is widened once.  (In 64 bits the sixteen rows of a 1-byte
+	// chunk took k_analyze<u8> to 132 VGPRs, three waves per SIMD.)
+	using X = typename std::conditional<sizeof(U) == 8, uint64_t, uint32_t>::type;
+	__shared__ X pmin[kWorkgroup / 64], pmax[kWorkgroup / 64];
 	const TileCtx t = resolve_tile<TILE>(descs, tiles);
 	const U *src = vals + t.elem0;
 	const uint32_t align = (uint32_t)(t.elem0 & (K - 1));
-	uint64_t mn = ~0ull, mx = 0;
+	const X flip = rule == ADAC_RULE_ZONEMAP ? (X)null_bits : (X)0; // the zonemap's order-preserving bias (T's sign bit)
+	X mn = ~(X)0, mx = 0; // "nothing seen": mn > mx
 	if (t.n == (uint32_t)TILE && align == 0 && validity == nullptr) {
 		// full, aligned, all-valid tile: the four 16-byte loads of a lane are issued back to back
 		constexpr int ROUNDS = TILE / (kWorkgroup * K);
@@ -1046,8 +1102,7 @@ __global__ __launch_bounds__(kWorkgroup) void k_analyze(const adac_segment_desc 
 			__builtin_memcpy(v, &q[r], 16);
 #pragma unroll
 			for (int j = 0; j < K; j++) {
-				const uint64_t x = rule == ADAC_RULE_ZONEMAP ? ((uint64_t)v[j] ^ null_bits)
-				                   : (rule == ADAC_RULE_APPEND && sign_extend) ? (uint64_t)(int64_t)(S)v[j] : (uint64_t)v[j];
+				const X x = (X)v[j] ^ flip;
 				mn = x < mn ? x : mn;
 				mx = x > mx ? x : mx;
 			}
@@ -1062,26 +1117,26 @@ __global__ __launch_bounds__(kWorkgroup) void k_analyze(const adac_segment_desc 
 		for (int j = 0; j < K; j++) {
 			if ((uint32_t)(base + j) >= t.n) continue;
 			const bool valid = (vbits >> j) & 1u;
-			uint64_t x;
-			if (rule == ADAC_RULE_ZONEMAP) {
-				// NumericStatistics::Update<T> (numeric_statistics.hpp:54-67): typed min/max over the valid rows,
-				// here in the order-preserving biased form bits(v) ^ signbit (null_bits IS the sign bit of T)
-				if (!valid) continue;
-				x = (uint64_t)v[j] ^ null_bits;
-			} else if (rule == ADAC_RULE_APPEND) {
-				// succinct.cpp:286-287: uint64_t(sdata[i]); NULL rows do not take part
-				if (!valid) continue;
-				x = sign_extend ? (uint64_t)(int64_t)(S)v[j] : (uint64_t)v[j];
-			} else {
+			X x;
+			if (rule == ADAC_RULE_RECOMPACT) {
 				// column_segment.cpp:392-399: every slot, zero-extended; NULL slots hold NullValue<T>
-				x = valid ? (uint64_t)v[j] : null_bits;
+				x = valid ? (X)v[j] : (X)null_bits;
+			} else {
+				// NumericStatistics::Update<T> (numeric_statistics.hpp:54-67): typed min/max over the valid rows, in the
+				// biased form bits(v) ^ signbit; succinct.cpp:286-287: uint64_t(sdata[i]), NULL rows do not take part
+				if (!valid) continue;
+				x = (X)v[j] ^ flip;
 			}
 			mn = x < mn ? x : mn;
 			mx = x > mx ? x : mx;
 		}
 	}
-	mn = wave_min(mn);
-	mx = wave_max(mx);
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) {
+		const X omn = __shfl_xor(mn, off, 64), omx = __shfl_xor(mx, off, 64);
+		mn = omn < mn ? omn : mn;
+		mx = omx > mx ? omx : mx;
+	}
 	if ((threadIdx.x & 63) == 0) {
 		pmin[threadIdx.x >> 6] = mn;
 		pmax[threadIdx.x >> 6] = mx;
@@ -1093,8 +1148,15 @@ __global__ __launch_bounds__(kWorkgroup) void k_analyze(const adac_segment_desc 
 			mn = pmin[i] < mn ? pmin[i] : mn;
 			mx = pmax[i] > mx ? pmax[i] : mx;
 		}
-		atomicMin(reinterpret_cast<unsigned long long *>(minmax + 2 * (uint64_t)t.seg), (unsigned long long)mn);
-		atomicMax(reinterpret_cast<unsigned long long *>(minmax + 2 * (uint64_t)t.seg + 1), (unsigned long long)mx);
+		if (mn <= mx) { // something was seen (otherwise the atomics would be no-ops on the initial ~0 / 0 anyway)
+			uint64_t mn64 = mn, mx64 = mx;
+			if (sizeof(U) < 8 && rule == ADAC_RULE_APPEND && sign_extend) {
+				mn64 = (uint64_t)(int64_t)(S)(U)mn;
+				mx64 = (uint64_t)(int64_t)(S)(U)mx;
+			}
+			atomicMin(reinterpret_cast<unsigned long long *>(minmax + 2 * (uint64_t)t.seg), (unsigned long long)mn64);
+			atomicMax(reinterpret_cast<unsigned long long *>(minmax + 2 * (uint64_t)t.seg + 1), (unsigned long long)mx64);
+		}
 	}
 }
 
@@ -1325,7 +1387,7 @@ __global__ __launch_bounds__(kWorkgroup) void k_repack(const adac_segment_desc *
 	__shared__ uint4 lds[kTileBytes / 16 + 2];
 	__shared__ __attribute__((aligned(16))) U delta[TILE];
 	const TileCtx t = resolve_tile<TILE>(src_descs, tiles);
-	const adac_segment_desc dd = dst_descs[t.seg];
+	const adac_segment_desc dd = load_desc(dst_descs + t.seg);
 	const uint32_t w = dd.width;
 	const bool packed = (dd.flags & ADAC_SEG_PACKED) != 0;
 	const U sub = (U)((packed && dd.min != ADAC_NO_MIN) ? dd.min : 0ull); // column_segment.cpp:371-373
@@ -1690,9 +1752,9 @@ __global__ __launch_bounds__(kWorkgroup) void k_repack_g(const ScanGroup *__rest
 	constexpr uint32_t kStageBytes = kTileBytes / 2;
 	__shared__ uint4 lds[kStageBytes / 16 + 2];
 	__shared__ __attribute__((aligned(16))) unsigned long long img[kImgWords];
-	const ScanGroup g = src_groups[blockIdx.x];
+	const ScanGroup g = load_scan_group(src_groups, blockIdx.x);
 	const adac_segment_desc &sd = g.d;
-	const adac_segment_desc dd = dst_descs[g.seg];
+	const adac_segment_desc dd = load_desc(dst_descs + g.seg);
 	const uint32_t w_old = sd.width, w = dd.width;
 	const bool packed = (dd.flags & ADAC_SEG_PACKED) != 0;
 	const U sub = (U)((packed && dd.min != ADAC_NO_MIN) ? dd.min : 0ull); // column_segment.cpp:371-373
@@ -1804,7 +1866,7 @@ __global__ __launch_bounds__(kWorkgroup) void k_analyze_packed_g(const ScanGroup
 	using S = typename std::make_signed<U>::type;
 	__shared__ uint4 lds[kTileBytes / 16 + 2];
 	__shared__ uint64_t pmin[kWorkgroup / 64], pmax[kWorkgroup / 64];
-	const ScanGroup g = src_groups[blockIdx.x];
+	const ScanGroup g = load_scan_group(src_groups, blockIdx.x);
 	const adac_segment_desc &sd = g.d;
 	const uint32_t w_old = sd.width;
 	const uint64_t add = effective_add(sd);
@@ -1922,14 +1984,34 @@ hipError_t dispatch_size(uint32_t type_size, F &&f) {
 #include "adac_encode_1p.inl"
 #include "adac_group_sum.inl"
 
+} // namespace
+
+Tuning g_tuning;
+
+namespace {
+
+// Compute units of the CURRENT device (every launcher runs after hipSetDevice(ctx->device)): the persistent kernels
+// size their grids from it — 256 on a whole MI355X, fewer on a partitioned one (CPX / DPX) — so that "one workgroup
+// per CU, all resident" holds on whatever device the pool lives on.  adac_set_tuning("num_cus", n > 0) overrides.
+uint64_t device_cus() {
+	if (g_tuning.num_cus > 0) return (uint64_t)g_tuning.num_cus;
+	static int cached[64]; // 0 = not asked yet; benign race: every thread writes the same value
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+	if (cached[dev] == 0) {
+		int n = 0;
+		if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+		cached[dev] = n;
+	}
+	return (uint64_t)cached[dev];
+}
+
 unsigned persistent_grid(uint64_t ntiles) {
-	const uint64_t cap = (uint64_t)g_tuning.num_cus * (uint64_t)g_tuning.blocks_per_cu;
+	const uint64_t cap = device_cus() * (uint64_t)g_tuning.blocks_per_cu;
 	return (unsigned)(ntiles < cap ? ntiles : cap);
 }
 
 } // namespace
-
-Tuning g_tuning;
 
 hipError_t launch_minmax_init(hipStream_t s, uint64_t *d_minmax, uint64_t nseg) {
 	if (nseg == 0) return hipSuccess;
@@ -2001,7 +2083,7 @@ hipError_t launch_encode_1p(hipStream_t s, uint32_t type_size, bool sign_extend,
 	hipError_t e = hipMemsetAsync(d_scan_state, 0, (nseg + 2) * sizeof(unsigned long long), s);
 	if (e != hipSuccess) return e;
 	// persistent: one workgroup per CU (a segment fills half a CU's register file), segments handed out by ticket
-	const uint64_t cus = g_tuning.num_cus > 0 ? (uint64_t)g_tuning.num_cus : 256;
+	const uint64_t cus = device_cus();
 	const unsigned grid = (unsigned)(nseg < cus ? nseg : cus);
 	return dispatch_size(type_size, [&](auto tag) {
 		using U = decltype(tag);
@@ -2028,7 +2110,7 @@ hipError_t launch_group_sum(hipStream_t s, uint32_t v_type_size, bool v_signed, 
 	ty.wide_only = g_tuning.group_sum_wide ? 1u : 0u;
 	// persistent: as many workgroups as are resident at once (seven per CU: 21 KiB of LDS each), so nobody runs a
 	// second round on a third of the chip
-	uint64_t cap = 7ull * (uint64_t)(g_tuning.num_cus > 0 ? g_tuning.num_cus : 256);
+	uint64_t cap = 7ull * device_cus();
 	cap = cap < kGroupMaxWorkgroups ? cap : kGroupMaxWorkgroups;
 	const uint32_t nwg = (uint32_t)(ntiles < cap ? ntiles : cap);
 	unsigned long long *partial = static_cast<unsigned long long *>(d_partial);
@@ -2124,31 +2206,37 @@ hipError_t launch_fetch(hipStream_t s, uint32_t type_size, const adac_segment_de
 }
 
 hipError_t launch_expand_groups(hipStream_t s, const adac_segment_desc *d_descs, const ScanGroupRef *d_refs,
-                                uint64_t ngroups, ScanGroup *d_groups) {
-	if (ngroups == 0) return hipSuccess;
+                                uint64_t ngroups, ScanGroup *d_groups, uint32_t *d_narrow_idx, uint32_t *d_narrow_count) {
+	hipError_t e = hipMemsetAsync(d_narrow_count, 0, sizeof(uint32_t), s);
+	if (e != hipSuccess || ngroups == 0) return e;
 	hipLaunchKernelGGL(k_expand_groups, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, s, d_descs, d_refs,
-	                   ngroups, d_groups);
+	                   ngroups, d_groups, d_narrow_idx, d_narrow_count);
 	return hipGetLastError();
 }
 
-hipError_t launch_scan_sum(hipStream_t s, uint32_t type_size, const ScanGroup *d_groups, uint64_t ngroups,
-                           const uint64_t *d_words, const uint64_t *d_validity, uint64_t sbit, uint64_t *d_sums) {
-	if (ngroups == 0) return hipSuccess;
+hipError_t launch_scan_sum(hipStream_t s, uint32_t type_size, const ScanGroupList &gl, const uint64_t *d_words,
+                           const uint64_t *d_validity, uint64_t sbit, uint64_t *d_sums) {
+	if (gl.ngroups == 0) return hipSuccess;
 	const RangePred widen {0ull, 0ull, sbit}; // SUM only needs T's sign bit
 	return dispatch_size(type_size, [&](auto tag) {
 		using U = decltype(tag);
-		const dim3 grid((unsigned)ngroups);
+		const dim3 grid((unsigned)gl.ngroups);
 		const int tpl = g_tuning.templated_scan;
 		uint32_t *no_bitmap = nullptr;
+		SelEdge *no_edges = nullptr;
 		if (g_tuning.scan_probe) { // diagnostic: the scan's loop and loads without the field walk (result meaningless)
-			hipLaunchKernelGGL((k_scan_agg<U, 2, false>), grid, dim3(kWorkgroup), 0, s, d_groups, 1, d_words, RangePred {},
-			                   static_cast<const uint64_t *>(nullptr), d_sums, no_bitmap, static_cast<SelEdge *>(nullptr));
+			hipLaunchKernelGGL((k_scan_agg<U, 2, false, false>), grid, dim3(kWorkgroup), 0, s, gl.d_groups, gl.d_narrow_idx,
+			                   1, d_words, RangePred {}, static_cast<const uint64_t *>(nullptr), d_sums, no_bitmap, no_edges);
 		} else if (d_validity) {
-			hipLaunchKernelGGL((k_scan_agg<U, 0, true>), grid, dim3(kWorkgroup), 0, s, d_groups, tpl, d_words, widen,
-			                   d_validity, d_sums, no_bitmap, static_cast<SelEdge *>(nullptr));
+			hipLaunchKernelGGL((k_scan_agg<U, 0, true, false>), grid, dim3(kWorkgroup), 0, s, gl.d_groups, gl.d_narrow_idx,
+			                   tpl, d_words, widen, d_validity, d_sums, no_bitmap, no_edges);
 		} else {
-			hipLaunchKernelGGL((k_scan_agg<U, 0, false>), grid, dim3(kWorkgroup), 0, s, d_groups, tpl, d_words, widen,
-			                   d_validity, d_sums, no_bitmap, static_cast<SelEdge *>(nullptr));
+			hipLaunchKernelGGL((k_scan_agg<U, 0, false, false>), grid, dim3(kWorkgroup), 0, s, gl.d_groups, gl.d_narrow_idx,
+			                   tpl, d_words, widen, d_validity, d_sums, no_bitmap, no_edges);
+			if (gl.n_narrow) {
+				hipLaunchKernelGGL((k_scan_agg<U, 0, false, true>), dim3(gl.n_narrow), dim3(kWorkgroup), 0, s, gl.d_groups,
+				                   gl.d_narrow_idx, tpl, d_words, widen, d_validity, d_sums, no_bitmap, no_edges);
+			}
 		}
 		return hipGetLastError();
 	});
@@ -2164,19 +2252,27 @@ hipError_t launch_sel_merge_edges(hipStream_t s, const void *d_edges, uint64_t n
 	return hipGetLastError();
 }
 
-hipError_t launch_scan_count_range(hipStream_t s, uint32_t type_size, const ScanGroup *d_groups, uint64_t ngroups,
-                                   const uint64_t *d_words, const uint64_t *d_validity, uint64_t blo, uint64_t bspan,
-                                   uint64_t sbit, uint64_t *d_counts, uint64_t *d_bitmap, void *d_edges) {
-	if (ngroups == 0) return hipSuccess;
+hipError_t launch_scan_count_range(hipStream_t s, uint32_t type_size, const ScanGroupList &gl, const uint64_t *d_words,
+                                   const uint64_t *d_validity, uint64_t blo, uint64_t bspan, uint64_t sbit,
+                                   uint64_t *d_counts, uint64_t *d_bitmap, void *d_edges) {
+	if (gl.ngroups == 0) return hipSuccess;
 	return dispatch_size(type_size, [&](auto tag) {
 		using U = decltype(tag);
-		const dim3 grid((unsigned)ngroups);
+		const dim3 grid((unsigned)gl.ngroups);
 		const RangePred pred {blo, bspan, sbit};
 		uint32_t *bm = reinterpret_cast<uint32_t *>(d_bitmap);
 		const int tpl = g_tuning.templated_scan | ((g_tuning.sel_debug == 5 ? 0 : g_tuning.sel_debug) << 1);
+		// the common kernel over every group (it leaves the groups at widths 2 and 3 alone), then the narrow one over those
 #define ADAC_SCAN(OPN, VAL)                                                                                            \
-	hipLaunchKernelGGL((k_scan_agg<U, OPN, VAL>), grid, dim3(kWorkgroup), 0, s, d_groups, tpl, d_words, pred,         \
-	                   d_validity, d_counts, bm, static_cast<SelEdge *>(d_edges))
+	do {                                                                                                               \
+		hipLaunchKernelGGL((k_scan_agg<U, OPN, VAL, false>), grid, dim3(kWorkgroup), 0, s, gl.d_groups, gl.d_narrow_idx, \
+		                   tpl, d_words, pred, d_validity, d_counts, bm, static_cast<SelEdge *>(d_edges));               \
+		if (gl.n_narrow) {                                                                                             \
+			hipLaunchKernelGGL((k_scan_agg<U, OPN, VAL, true>), dim3(gl.n_narrow), dim3(kWorkgroup), 0, s, gl.d_groups,  \
+			                   gl.d_narrow_idx, tpl, d_words, pred, d_validity, d_counts, bm,                            \
+			                   static_cast<SelEdge *>(d_edges));                                                         \
+		}                                                                                                              \
+	} while (0)
 		if (d_bitmap) {
 			if (d_validity) ADAC_SCAN(3, true); else ADAC_SCAN(3, false);
 		} else {

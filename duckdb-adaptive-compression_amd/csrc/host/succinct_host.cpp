@@ -1847,6 +1847,46 @@ extern "C" int adach_segment_scan(adach_segment *s, uint64_t row_index, uint64_t
 	});
 }
 
+// The scan state of ONE scanning thread as the engine keeps it (ColumnScanState, scan_state.hpp): init_scan's result
+// lives in it from one scan_vector call to the next, which is what lets it pin the decoded block of the segment.
+struct adach_scan_state {
+	ColumnScanState st;
+};
+
+extern "C" adach_scan_state *adach_scan_state_create(void) {
+	return new (std::nothrow) adach_scan_state();
+}
+
+extern "C" void adach_scan_state_destroy(adach_scan_state *st) {
+	delete st; // releases the pin
+}
+
+extern "C" int adach_segment_init_scan(adach_segment *s, adach_scan_state *st) {
+	return Guard([&]() {
+		st->st.current = s->seg.get();
+		s->seg->InitializeScan(st->st); // replaces (and thereby unpins) what the state held for the previous segment
+	});
+}
+
+extern "C" int adach_segment_scan_with(adach_segment *s, adach_scan_state *st, uint64_t row_index, uint64_t count,
+                                       void *result, uint64_t result_offset, int entire_vector) {
+	return Guard([&]() {
+		if (st->st.current != s->seg.get() || !st->st.scan_state) throw InternalException("scan state of another segment");
+		st->st.row_index = row_index;
+		Vector v;
+		v.data = static_cast<data_ptr_t>(result);
+		s->seg->Scan(st->st, count, v, result_offset, entire_vector != 0);
+	});
+}
+
+extern "C" int adach_segments_compact(adach_db *h, adach_segment **segs, uint64_t nseg) {
+	return Guard([&]() {
+		std::vector<ColumnSegment *> list;
+		for (uint64_t i = 0; i < nseg; i++) list.push_back(segs[i]->seg.get());
+		ColumnSegment::CompactMany(*h->db, list);
+	});
+}
+
 extern "C" int adach_segment_fetch_row(adach_segment *s, int64_t row_id, void *result, uint64_t result_idx) {
 	return Guard([&]() {
 		ColumnFetchState st;

@@ -43,6 +43,11 @@ HOST_SIGNATURES = {
     "adach_segment_append": (_i64, [_vp, _vp, _vp, _vp, _u64, _u64]),
     "adach_segment_scan": (_int, [_vp, _u64, _u64, _vp, _u64, _int]),
     "adach_segment_fetch_row": (_int, [_vp, _i64, _vp, _u64]),
+    "adach_scan_state_create": (_vp, []),
+    "adach_scan_state_destroy": (None, [_vp]),
+    "adach_segment_init_scan": (_int, [_vp, _vp]),
+    "adach_segment_scan_with": (_int, [_vp, _vp, _u64, _u64, _vp, _u64, _int]),
+    "adach_segments_compact": (_int, [_vp, C.POINTER(_vp), _u64]),
     "adach_segment_compact": (_int, [_vp]),
     "adach_segment_uncompact": (_int, [_vp]),
     "adach_segment_count": (_u64, [_vp]),
@@ -86,6 +91,24 @@ def _ok(rc, where):
 
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class ScanState:
+    """duckdb::ColumnScanState of one scanning thread (adach_scan_state)."""
+
+    def __init__(self):
+        self._h = hlib().adach_scan_state_create()
+
+    def close(self):
+        if self._h:
+            hlib().adach_scan_state_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pragma: no cover
+            pass
 
 
 class Database:
@@ -248,6 +271,11 @@ class Database:
                                       C.byref(rows)), "full_scan")
         return cs.value, sec.value, rows.value
 
+    def compact_segments(self, segments):
+        """ColumnSegment::CompactMany over a list: one upload / analyze / pack per (pool, type, rule)."""
+        arr = (_vp * len(segments))(*[s._h for s in segments])
+        _ok(hlib().adach_segments_compact(self._h, arr, len(segments)), "CompactMany")
+
     def compact_all(self):
         _ok(hlib().adach_catalog_compact_all(self._h), "CompactAllSegments")
 
@@ -305,6 +333,17 @@ class Segment:
             result = np.empty(result_offset + count, dtype=self.dtype)
         _ok(hlib().adach_segment_scan(self._h, self.start + row, count, _p(result), result_offset, int(entire_vector)),
             "Scan")
+        return result[result_offset:result_offset + count]
+
+    def init_scan(self, state):
+        """ColumnSegment::InitializeScan into a ScanState that lives across scan calls (and pins the decoded block)."""
+        _ok(hlib().adach_segment_init_scan(self._h, state._h), "InitializeScan")
+
+    def scan_with(self, state, row, count, result, result_offset=0, entire_vector=None):
+        if entire_vector is None:
+            entire_vector = result_offset == 0
+        _ok(hlib().adach_segment_scan_with(self._h, state._h, self.start + row, count, _p(result), result_offset,
+                                           int(entire_vector)), "Scan")
         return result[result_offset:result_offset + count]
 
     def fetch_row(self, row):

@@ -89,6 +89,19 @@ class Comm:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return int(t.item())
 
+    def gather_rows(self, row):
+        """One short list of numbers per rank -> the list of every rank's list, on every rank (all_gather of a small
+        float64 tensor: rows and byte counts stay exact below 2^53)."""
+        row = [float(x) for x in row]
+        if self.dist is None:
+            return [row]
+        import torch
+        dev = "cuda:%d" % self.device if self.backend == "nccl" else "cpu"
+        mine = torch.tensor(row, dtype=torch.float64, device=dev)
+        out = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(out, mine)
+        return [t.cpu().tolist() for t in out]
+
     def sum_u64(self, x):
         """Sum mod 2^64 of one unsigned 64-bit value per rank (checksum of checksums): reduced as two 32-bit halves
         so that no backend's integer overflow behaviour matters."""

@@ -197,17 +197,6 @@ adac_status adac_event_wait(adac_event *ev);
 int adac_event_done(adac_event *ev); /* 1 finished, 0 still running (or error) */
 void adac_event_destroy(adac_event *ev);
 
-/* HIP-graph capture of a sequence of enqueue calls on the context's stream (any of the hot-path calls below,
- * after one eager warm-up run so that lazily built launch tables exist; calls that return results to the host —
- * adac_zonemap, adac_layout_get_*, adac_unpack_selected with total_out — cannot be captured).  Replaying the
- * graph costs one launch instead of one per memset/kernel: what short multi-scan pipelines are bound by.
- * Pointers are baked in: replay with the same buffers. */
-typedef struct adac_graph adac_graph;
-adac_status adac_capture_begin(adac_ctx *ctx);
-adac_status adac_capture_end(adac_ctx *ctx, adac_graph **out);
-adac_status adac_graph_launch(adac_graph *graph);
-void adac_graph_destroy(adac_graph *graph);
-
 /* HIP-event stopwatch on the ctx stream (for measuring kernels where they are launched). */
 adac_status adac_timer_start(adac_ctx *ctx);
 adac_status adac_timer_stop(adac_ctx *ctx, float *elapsed_ms); /* records, synchronises, reads */

@@ -109,6 +109,24 @@ int64_t adach_segment_append(adach_segment *seg, const void *vals, const uint64_
 int adach_segment_scan(adach_segment *seg, uint64_t row_index, uint64_t count, void *result, uint64_t result_offset,
                        int entire_vector);
 int adach_segment_fetch_row(adach_segment *seg, int64_t row_id, void *result, uint64_t result_idx);
+
+/* The engine's scan state (duckdb::ColumnScanState, src/include/duckdb/storage/table/scan_state.hpp) as an object that
+ * lives across scan_vector calls: adach_segment_init_scan is ColumnSegment::InitializeScan (column_segment.cpp:133-135
+ * -> init_scan slot) — ColumnData::ScanVector calls it whenever it moves on to the next segment
+ * (src/storage/table/column_data.cpp:92-139) — and the state then PINS the segment's decoded block in the page-locked
+ * cache on its first scan, so every following 2048-row call is a memcpy.  adach_segment_scan (above) builds a fresh
+ * state per call and is the uncached shape; integration/succinct_gpu.cpp uses the calls below.  One state per
+ * scanning thread; destroying it (or initialising it for another segment) releases the pin. */
+typedef struct adach_scan_state adach_scan_state;
+adach_scan_state *adach_scan_state_create(void);
+void adach_scan_state_destroy(adach_scan_state *state);
+int adach_segment_init_scan(adach_segment *seg, adach_scan_state *state);
+int adach_segment_scan_with(adach_segment *seg, adach_scan_state *state, uint64_t row_index, uint64_t count,
+                            void *result, uint64_t result_offset, int entire_vector);
+/* ColumnSegment::Compact for a list of segments of any pools: one upload, one analyze, one pack per (pool, type,
+ * rule) — what CompactAllSegments and a policy round of the engine's own catalog hand over
+ * (src/catalog/catalog_entry/column_segment_catalog.cpp:56-116) */
+int adach_segments_compact(adach_db *db, adach_segment **segs, uint64_t nseg);
 int adach_segment_compact(adach_segment *seg);
 int adach_segment_uncompact(adach_segment *seg);
 uint64_t adach_segment_count(adach_segment *seg);

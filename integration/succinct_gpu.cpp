@@ -1,18 +1,25 @@
-// succinct_gpu.cpp — the DuckDB-side adapter of INTEGRATION.md as real code: the callbacks of
-// src/storage/compression/succinct.cpp (reference) re-implemented on libadacodec's C ABI, written against the
-// reference's OWN headers.  It is not built into libadacodec (that would need the DuckDB tree); the test
-// tests/test_integration_adapter.py syntax-checks it with the reference's include directories when the reference
-// checkout is present, so every signature below is checked against duckdb::CompressionFunction's slot typedefs
-// (src/include/duckdb/function/compression_function.hpp:65-103) and ColumnSegment's members
-// (src/include/duckdb/storage/table/column_segment.hpp:40-214).
+// succinct_gpu.cpp — the DuckDB-side adapter of INTEGRATION.md as real code: the replacement of the reference's
+// src/storage/compression/succinct.cpp, written against the reference's OWN headers, as a THIN SHIM over the host
+// mirror's C interface (include/adacodec_host.h).  Every callback below forwards to the adach_* call that
+// tests/test_gpu_host_mirror.py and tests/test_gpu_adapter_sequence.py drive on the GPU, so the DuckDB-typed slots
+// inherit exactly the tested code: pools per GPU, the arena free list, batched compaction, the scan lanes, the
+// page-locked decoded-segment cache, representation versions and locks.  Nothing here touches a device, stages a
+// row or decides a width itself.
 //
-// What changes inside the reference when this file replaces succinct.cpp:
-//   * ColumnSegment::succinct_vec (sdsl::int_vector<>) is no longer used: the bits live in HBM, the per-segment
-//     handle is the CompressedSegmentState returned by the init_segment slot (SuccinctInitSegment);
-//   * ColumnSegment::Compact() / Uncompact() (column_segment.cpp:273-346) call SuccinctCompactOnDevice /
-//     SuccinctUncompactFromDevice instead of BitCompressFromSuccinct / UncompressSuccinct, and
-//     ColumnSegmentCatalog::CompactAllSegments / CompressLowestKSegments (column_segment_catalog.cpp:56-116) hand
-//     their whole list to SuccinctCompactManyOnDevice (one upload + one pack launch per pool and type).
+// It is not built into libadacodec (that would need the DuckDB tree): tests/test_integration_adapter.py compiles it
+// to an object (g++ -c) with the reference's include directories whenever the reference checkout is present, so every
+// slot is checked against duckdb::CompressionFunction's typedefs (src/include/duckdb/function/
+// compression_function.hpp:65-103) and every member used against ColumnSegment (src/include/duckdb/storage/table/
+// column_segment.hpp:40-214).
+//
+// What changes inside the reference when this file replaces succinct.cpp (INTEGRATION.md §2 has the patch lines):
+//   * ColumnSegment::succinct_vec is no longer used: a segment's rows live in its mirror segment (adach_segment),
+//     held by the CompressedSegmentState the init_segment slot returns;
+//   * ColumnSegment::BitCompressFromSuccinct / BitCompressFromUncompressed / UncompressSuccinct
+//     (column_segment.cpp:348-506) become calls of SuccinctCompactOnDevice / SuccinctAdoptUncompressed /
+//     SuccinctRestoreUncompressed below; GetDataSize / SuccinctSize (column_segment.cpp:204-222) ask SuccinctDataSize;
+//   * ColumnSegmentCatalog::CompactAllSegments and a policy round (column_segment_catalog.cpp:56-116) hand their lists
+//     to SuccinctCompactManyOnDevice: one upload, one analyze and one pack launch per pool and type.
 #include "duckdb/common/types/null_value.hpp"
 #include "duckdb/common/types/vector.hpp"
 #include "duckdb/function/compression/compression.hpp"
@@ -21,171 +28,114 @@
 #include "duckdb/main/database.hpp"
 #include "duckdb/storage/buffer_manager.hpp"
 #include "duckdb/storage/segment/uncompressed.hpp"
+#include "duckdb/storage/statistics/numeric_statistics.hpp"
 #include "duckdb/storage/table/append_state.hpp"
 #include "duckdb/storage/table/column_segment.hpp"
 #include "duckdb/storage/table/scan_state.hpp"
 
-#include "adacodec.h" // this repository's include/
+#include "adacodec.h"      // adac_device_count only (this repository's include/)
+#include "adacodec_host.h" // everything else
 
-#include <atomic>
 #include <cstdlib>
-#include <cstring>
 #include <map>
 #include <mutex>
 #include <vector>
 
 namespace duckdb {
 
-static void AdacCheck(adac_status st, const char *what) {
-	if (st != ADAC_OK) {
-		throw InternalException(string("adacodec: ") + what + ": " + adac_status_string(st) + " (" + adac_last_error() + ")");
+static void AdachCheck(int rc, const char *what) {
+	if (rc != 0) {
+		throw InternalException(string("adacodec: ") + what + ": " + adach_last_error());
 	}
 }
 
 //===--------------------------------------------------------------------===//
-// Per-GPU segment pools: context, packed arena with a first-fit free list (blocks return to it when a segment is
-// expanded or destroyed), device staging.  One pool per visible gfx950 device (adac_device_count()), created on first
-// use; a segment is bound to pool (creation counter mod pools) for its whole life — segments are independent units
-// (src/storage/table/row_group_collection.cpp:119-155), so nothing ever crosses between pools.
-// csrc/host/succinct_host.cpp is the tested implementation of the same design (plus the decoded-segment cache and
-// the scan lanes); this file is its shape against DuckDB's real types.
+// One mirror database (adach_db: one segment pool per visible gfx950 device, adacodec_host.h) per DuckDB instance,
+// created on first use from the instance's own DBConfig flags (config.hpp:189-197).  Sizes come from the environment:
+// ADAC_ARENA_BYTES (packed arena per GPU, default 8 GiB of the 288 GB) and ADAC_DECODED_CACHE_BYTES (page-locked
+// host memory per GPU for decoded segments, default 1 GiB).  There is no CPU fallback: without a device the
+// function table cannot be used and the first segment throws.
 //===--------------------------------------------------------------------===//
-class SuccinctDevicePool {
+class SuccinctMirror {
 public:
-	explicit SuccinctDevicePool(int device_p, idx_t arena_bytes) : device(device_p) {
-		AdacCheck(adac_ctx_create(device, nullptr, &ctx), "adac_ctx_create"); // ADAC_ERR_NO_DEVICE: no CPU fallback
-		arena_words = (arena_bytes / 8 + 15) & ~uint64_t(15);
-		void *p = nullptr;
-		AdacCheck(adac_dev_alloc(ctx, arena_words * 8, &p), "adac_dev_alloc(arena)");
-		d_arena = (uint64_t *)p;
-		AdacCheck(adac_dev_memset(ctx, d_arena, 0, arena_words * 8), "adac_dev_memset(arena)");
-		free_list[0] = arena_words;
-	}
-	~SuccinctDevicePool() {
-		if (d_staging) {
-			adac_dev_free(ctx, d_staging);
+	static adach_db *Get(DatabaseInstance &db) {
+		static std::mutex lock;
+		static std::map<DatabaseInstance *, adach_db *> mirrors; // live as long as the process (the pools own HBM)
+		std::lock_guard<std::mutex> guard(lock);
+		auto entry = mirrors.find(&db);
+		if (entry != mirrors.end()) {
+			return entry->second;
 		}
-		if (d_arena) {
-			adac_dev_free(ctx, d_arena);
-		}
-		adac_ctx_destroy(ctx);
-	}
-	const int device;
-	adac_ctx *ctx = nullptr;
-	uint64_t *d_arena = nullptr;
-	uint64_t arena_words = 0;
-	std::mutex lock; // serialises the device work of this pool (one stream)
-
-	//! First fit over 128-byte units; false when no block is large enough (the segment then stays unpacked)
-	bool TryAllocate(uint64_t words, uint64_t &word_off) {
-		words = (words + 15) & ~uint64_t(15);
-		std::lock_guard<std::mutex> guard(arena_lock);
-		for (auto it = free_list.begin(); it != free_list.end(); ++it) {
-			if (it->second >= words) {
-				uint64_t off = it->first, len = it->second;
-				free_list.erase(it);
-				if (len > words) {
-					free_list[off + words] = len - words;
-				}
-				word_off = off;
-				return true;
-			}
-		}
-		return false;
-	}
-	void Free(uint64_t off, uint64_t words) {
-		words = (words + 15) & ~uint64_t(15);
-		std::lock_guard<std::mutex> guard(arena_lock);
-		auto next = free_list.lower_bound(off);
-		if (next != free_list.begin()) {
-			auto prev = std::prev(next);
-			if (prev->first + prev->second == off) {
-				off = prev->first;
-				words += prev->second;
-				free_list.erase(prev);
-			}
-		}
-		if (next != free_list.end() && off + words == next->first) {
-			words += next->second;
-			free_list.erase(next);
-		}
-		free_list[off] = words;
-	}
-	//! device scratch, grown on demand (call with `lock` held)
-	void *Staging(idx_t bytes) {
-		if (bytes > staging_bytes) {
-			if (d_staging) {
-				adac_dev_free(ctx, d_staging);
-				d_staging = nullptr;
-				staging_bytes = 0;
-			}
-			AdacCheck(adac_dev_alloc(ctx, bytes + 64, &d_staging), "adac_dev_alloc(staging)");
-			staging_bytes = bytes;
-		}
-		return d_staging;
-	}
-
-private:
-	std::mutex arena_lock;
-	std::map<uint64_t, uint64_t> free_list; // word offset -> length
-	void *d_staging = nullptr;
-	idx_t staging_bytes = 0;
-};
-
-class SuccinctDevicePools {
-public:
-	//! the pools of this process: one per device, arena size from ADAC_ARENA_BYTES (default 8 GiB of the 288 GB)
-	static SuccinctDevicePools &Get() {
-		static SuccinctDevicePools pools;
-		return pools;
-	}
-	SuccinctDevicePool &Next() {
-		return *pools[counter.fetch_add(1) % pools.size()];
-	}
-	std::vector<unique_ptr<SuccinctDevicePool>> pools;
-
-private:
-	SuccinctDevicePools() {
 		int n = adac_device_count();
 		if (n < 1) {
 			throw InternalException("adacodec: no gfx950 device (there is no CPU fallback)");
 		}
-		idx_t arena_bytes = idx_t(8) << 30;
-		if (const char *env = std::getenv("ADAC_ARENA_BYTES")) {
-			arena_bytes = (idx_t)std::strtoull(env, nullptr, 10);
-		}
+		std::vector<int> devices;
 		for (int d = 0; d < n; d++) {
-			pools.push_back(unique_ptr<SuccinctDevicePool>(new SuccinctDevicePool(d, arena_bytes)));
+			devices.push_back(d);
 		}
+		auto &config = DBConfig::GetConfig(db);
+		adach_db *mirror = adach_db_create_pools(
+		    devices.data(), n, config.succinct_enabled ? 1 : 0, config.adaptive_succinct_compression_enabled ? 1 : 0,
+		    config.succinct_padded_to_next_byte_enabled ? 1 : 0, EnvBytes("ADAC_ARENA_BYTES", uint64_t(8) << 30),
+		    EnvBytes("ADAC_DECODED_CACHE_BYTES", uint64_t(1) << 30), 0, 0);
+		if (!mirror) {
+			throw InternalException(string("adacodec: adach_db_create_pools: ") + adach_last_error());
+		}
+		mirrors[&db] = mirror;
+		return mirror;
 	}
-	std::atomic<uint64_t> counter {0};
+
+private:
+	static uint64_t EnvBytes(const char *name, uint64_t fallback) {
+		const char *env = std::getenv(name);
+		return env ? (uint64_t)std::strtoull(env, nullptr, 10) : fallback;
+	}
 };
 
 //===--------------------------------------------------------------------===//
-// Per-segment state (slot init_segment): replaces the succinct_vec member.  No device object per segment: the packed
-// form is a block of the pool's arena + the 32-byte descriptor; reads are layout-free jobs (adac_unpack_jobs).
+// Per-segment state (slot init_segment): the handle of the mirror segment, which replaces the succinct_vec member.
 //===--------------------------------------------------------------------===//
 struct SuccinctSegmentState : public CompressedSegmentState {
-	SuccinctSegmentState() : pool(SuccinctDevicePools::Get().Next()) {
+	explicit SuccinctSegmentState(adach_segment *handle_p) : handle(handle_p) {
 	}
 	~SuccinctSegmentState() override {
-		if (packed_on_device) {
-			pool.Free(desc.word_off, arena_words); // the block goes back to the pool with the segment
-		}
+		adach_segment_destroy(handle); // arena block and cache entry go back to the pool
 	}
-	SuccinctDevicePool &pool;
-	adac_segment_desc desc;        // word_off into the pool arena, count, width, min, flags
-	uint64_t arena_words = 0;
-	bool packed_on_device = false;
-	std::vector<data_t> staged;    // appended rows, raw, at 8 * sizeof(T) bits per slot
-	std::vector<uint64_t> validity; // one bit per staged row (all ones until a NULL arrives)
-	bool any_null = false;
+	adach_segment *handle;
 };
 
+static adach_segment *Handle(ColumnSegment &segment) {
+	auto state = (SuccinctSegmentState *)segment.GetSegmentState();
+	if (!state) {
+		throw InternalException("adacodec: succinct segment without its device state");
+	}
+	return state->handle;
+}
+
+static unique_ptr<CompressedSegmentState> SuccinctCreateState(ColumnSegment &segment) {
+	adach_segment *handle = adach_segment_create(SuccinctMirror::Get(segment.db), (int)segment.type.InternalType(),
+	                                             segment.start, segment.SegmentSize());
+	if (!handle) {
+		throw InternalException(string("adacodec: adach_segment_create: ") + adach_last_error());
+	}
+	return unique_ptr<CompressedSegmentState>(new SuccinctSegmentState(handle));
+}
+
 static unique_ptr<CompressedSegmentState> SuccinctInitSegment(ColumnSegment &segment, block_id_t block_id) {
-	auto state = make_unique<SuccinctSegmentState>();
-	state->staged.resize(segment.SegmentSize());
-	return move(state);
+	return SuccinctCreateState(segment);
+}
+
+//! what the mirror knows after a flip goes back into the members the engine reads (column_segment.hpp:139-171)
+static void SuccinctSyncMembers(ColumnSegment &segment) {
+	adach_segment *handle = Handle(segment);
+	segment.UpdateMinFactor(adach_segment_min(handle));
+	segment.UpdateMaxFactor(adach_segment_max(handle));
+	if (adach_segment_compacted(handle)) {
+		segment.SetBitCompressed();
+	} else {
+		segment.SetBitUncompressed();
+	}
 }
 
 //===--------------------------------------------------------------------===//
@@ -208,8 +158,10 @@ static idx_t SuccinctFinalAnalyze(AnalyzeState &state_p) {
 }
 
 //===--------------------------------------------------------------------===//
-// Append (succinct.cpp:264-330): rows are staged raw, no arithmetic on the host — min/max come from adac_analyze
-// when the segment compacts
+// Append (succinct.cpp:264-330).  The rows go to the mirror segment (ColumnSegment::Append of the mirror: staging
+// through the selection vector and the validity mask, NullValue<T> in the NULL slots, no arithmetic — min / max come
+// from the device when the segment compacts); the engine's zonemap statistics are kept here, as the reference's
+// append loop keeps them (succinct.cpp:284,299).
 //===--------------------------------------------------------------------===//
 static unique_ptr<CompressionAppendState> SuccinctInitAppend(ColumnSegment &segment) {
 	auto &buffer_manager = BufferManager::GetBufferManager(segment.db);
@@ -220,35 +172,21 @@ static unique_ptr<CompressionAppendState> SuccinctInitAppend(ColumnSegment &segm
 template <class T>
 static idx_t SuccinctAppend(CompressionAppendState &append_state, ColumnSegment &segment, SegmentStatistics &stats,
                             UnifiedVectorFormat &data, idx_t offset, idx_t count) {
-	auto &state = (SuccinctSegmentState &)*segment.GetSegmentState();
-	idx_t max_tuple_count = segment.SegmentSize() / sizeof(T);
-	idx_t copy_count = MinValue<idx_t>(count, max_tuple_count - segment.count);
-	if (state.validity.empty()) {
-		state.validity.assign((max_tuple_count + 63) / 64 + 1, ~uint64_t(0));
+	const validity_t *validity = data.validity.AllValid() ? nullptr : data.validity.GetData();
+	int64_t copied = adach_segment_append(Handle(segment), data.data, validity, data.sel->data(), offset, count);
+	if (copied < 0) {
+		throw InternalException(string("adacodec: adach_segment_append: ") + adach_last_error());
 	}
 	auto sdata = (T *)data.data;
-	auto tdata = (T *)state.staged.data();
-	// the running min / max of SuccinctAppendLoop (succinct.cpp:286-299): uint64_t(T x), NULL rows excluded.  They
-	// ride along with the copy the slot has to make anyway, so Compact() needs no analyze pass over the rows
-	uint64_t min = segment.GetMinFactor(), max = segment.GetMax();
-	for (idx_t i = 0; i < copy_count; i++) {
+	for (idx_t i = 0; i < (idx_t)copied; i++) {
 		auto source_idx = data.sel->get_index(offset + i);
-		auto target_idx = segment.count + i;
 		if (data.validity.RowIsValid(source_idx)) {
-			tdata[target_idx] = sdata[source_idx];
-			uint64_t v = uint64_t(sdata[source_idx]);
-			min = MinValue<uint64_t>(min, v);
-			max = MaxValue<uint64_t>(max, v);
-		} else {
-			tdata[target_idx] = NullValue<T>(); // succinct.cpp:288-291
-			state.validity[target_idx >> 6] &= ~(uint64_t(1) << (target_idx & 63));
-			state.any_null = true;
+			NumericStatistics::Update<T>(stats, sdata[source_idx]);
 		}
 	}
-	segment.UpdateMinFactor(min); // succinct.cpp:317-318
-	segment.UpdateMaxFactor(max);
-	segment.count += copy_count;
-	return copy_count;
+	segment.count += copied;
+	SuccinctSyncMembers(segment); // the mirror compacts a segment that filled up (column_segment.cpp:266-268)
+	return (idx_t)copied;
 }
 
 template <class T>
@@ -257,173 +195,111 @@ static idx_t SuccinctFinalizeAppend(ColumnSegment &segment, SegmentStatistics &s
 }
 
 //===--------------------------------------------------------------------===//
-// Compact / Uncompact bodies for ColumnSegment (were BitCompressFromSuccinct / UncompressSuccinct).
-// A2: the append slot carried min / max, so compaction is the width decision on the host (adac_width,
-// column_segment.cpp:351-363) + ONE pack pass on the device; many segments of a pool go through one upload and one
-// launch (SuccinctCompactManyOnDevice: what CompactAllSegments and a policy round call).
+// Bodies for ColumnSegment's three private conversions (column_segment.cpp:348-506) and its size accounting
 //===--------------------------------------------------------------------===//
+
+//! BitCompressFromSuccinct for many segments: per (pool, type, rule) one upload, one analyze, one pack
 void SuccinctCompactManyOnDevice(const std::vector<ColumnSegment *> &segments) {
-	std::map<std::pair<SuccinctDevicePool *, int>, std::vector<ColumnSegment *>> groups; // (pool, physical type)
+	std::map<DatabaseInstance *, std::vector<ColumnSegment *>> by_db;
 	for (auto segment : segments) {
-		auto &state = (SuccinctSegmentState &)*segment->GetSegmentState();
-		if (!state.packed_on_device && segment->count > 0) {
-			groups[std::make_pair(&state.pool, (int)segment->type.InternalType())].push_back(segment);
+		if (segment->function->type == CompressionType::COMPRESSION_SUCCINCT && segment->GetSegmentState()) {
+			by_db[&segment->db].push_back(segment);
 		}
 	}
-	for (auto &group : groups) {
-		auto &pool = *group.first.first;
-		const int ptype = group.first.second;
-		const idx_t ts = adac_type_size(ptype);
-		const idx_t per16 = 16 / ts;
-		auto &config = DBConfig::GetConfig(group.second[0]->db);
-		std::vector<uint32_t> counts;
-		std::vector<uint64_t> offs;
-		std::vector<adac_segment_desc> descs;
-		std::vector<ColumnSegment *> packed;
-		uint64_t span = 0;
-		bool any_null = false;
-		for (auto segment : group.second) {
-			auto &state = (SuccinctSegmentState &)*segment->GetSegmentState();
-			const uint64_t mn = segment->GetMinFactor(), mx = segment->GetMax();
-			const uint8_t w = adac_width(mn, mx, ADAC_RULE_APPEND, config.succinct_padded_to_next_byte_enabled ? 1 : 0);
-			if (8 * ts <= w) { // `if (old_width > min_width)` fails (column_segment.cpp:363): the slots stay as they are
-				segment->SetBitCompressed();
-				continue;
-			}
-			adac_segment_desc d;
-			const uint64_t need = adac_arena_words(segment->count, w);
-			if (!pool.TryAllocate(need, d.word_off)) {
-				continue; // arena full: the segment keeps its unpacked form (tried again by the next round)
-			}
-			d.val_off = span;
-			d.min = adac_stored_min(mn, mx, w);
-			d.count = (uint32_t)segment->count;
-			d.width = w;
-			d.flags = ADAC_SEG_PACKED;
-			d.reserved = 0;
-			state.arena_words = need;
-			descs.push_back(d);
-			counts.push_back(d.count);
-			offs.push_back(span);
-			packed.push_back(segment);
-			span += (segment->count + per16 - 1) / per16 * per16; // every segment 16-byte aligned in the staging
-			any_null |= state.any_null;
+	for (auto &entry : by_db) {
+		std::vector<adach_segment *> handles;
+		for (auto segment : entry.second) {
+			handles.push_back(Handle(*segment));
 		}
-		if (packed.empty()) {
-			continue;
-		}
-		std::lock_guard<std::mutex> guard(pool.lock);
-		const idx_t bytes = span * ts + 16;
-		const idx_t vbytes = (span / 64 + 2) * 8;
-		auto d_vals = (data_ptr_t)pool.Staging(bytes + 64 + vbytes);
-		auto d_valid = (uint64_t *)(d_vals + ((bytes + 63) & ~idx_t(63)));
-		std::vector<uint64_t> vmask;
-		if (any_null) {
-			vmask.assign(vbytes / 8, ~uint64_t(0));
-		}
-		adac_layout *layout = nullptr;
-		try {
-			for (idx_t i = 0; i < packed.size(); i++) {
-				auto &state = (SuccinctSegmentState &)*packed[i]->GetSegmentState();
-				AdacCheck(adac_memcpy_h2d(pool.ctx, d_vals + offs[i] * ts, state.staged.data(), idx_t(counts[i]) * ts),
-				          "upload rows");
-				for (idx_t r = 0; state.any_null && r < counts[i]; r++) {
-					if (!((state.validity[r >> 6] >> (r & 63)) & 1)) {
-						vmask[(offs[i] + r) >> 6] &= ~(uint64_t(1) << ((offs[i] + r) & 63));
-					}
-				}
-			}
-			if (any_null) {
-				AdacCheck(adac_memcpy_h2d(pool.ctx, d_valid, vmask.data(), vbytes), "upload validity");
-			}
-			AdacCheck(adac_layout_create(pool.ctx, ptype, counts.data(), offs.data(), packed.size(), &layout),
-			          "adac_layout_create");
-			AdacCheck(adac_layout_set_descs(layout, descs.data()), "adac_layout_set_descs");
-			AdacCheck(adac_pack(layout, d_vals, any_null ? d_valid : nullptr, pool.d_arena), "adac_pack");
-			AdacCheck(adac_ctx_sync(pool.ctx), "adac_ctx_sync");
-		} catch (...) {
-			if (layout) {
-				adac_layout_destroy(layout);
-			}
-			for (auto &d : descs) {
-				pool.Free(d.word_off, adac_arena_words(d.count, d.width)); // nothing of the batch keeps its block
-			}
-			throw;
-		}
-		adac_layout_destroy(layout);
-		for (idx_t i = 0; i < packed.size(); i++) {
-			auto &state = (SuccinctSegmentState &)*packed[i]->GetSegmentState();
-			state.desc = descs[i];
-			state.desc.val_off = 0;
-			state.packed_on_device = true;
-			std::vector<data_t>().swap(state.staged); // the unpacked image is gone, as after SDSL's realloc shrink
-			packed[i]->SetBitCompressed();
+		AdachCheck(adach_segments_compact(SuccinctMirror::Get(*entry.first), handles.data(), handles.size()),
+		           "adach_segments_compact");
+		for (auto segment : entry.second) {
+			SuccinctSyncMembers(*segment); // a segment the arena had no room for stays unpacked and is tried again
 		}
 	}
 }
 
+//! column_segment.cpp:348 — void ColumnSegment::BitCompressFromSuccinct() { SuccinctCompactOnDevice(*this); }
 void SuccinctCompactOnDevice(ColumnSegment &segment) {
 	SuccinctCompactManyOnDevice(std::vector<ColumnSegment *> {&segment});
 }
 
-//! rows [start, start + count) of a packed segment into `target` (host memory)
-static void SuccinctDecodeRows(SuccinctSegmentState &state, PhysicalType type, idx_t type_size, idx_t start, idx_t count,
-                               data_ptr_t target) {
-	auto &pool = state.pool;
-	std::lock_guard<std::mutex> guard(pool.lock);
-	const idx_t bytes = count * type_size;
-	auto d_out = pool.Staging(bytes);
-	adac_unpack_job job;
-	memset(&job, 0, sizeof(job));
-	job.word_off = state.desc.word_off;
-	job.min = state.desc.min;
-	job.out_off = 0;
-	job.start = (uint32_t)start;
-	job.count = (uint32_t)count;
-	job.width = state.desc.width;
-	job.flags = state.desc.flags;
-	AdacCheck(adac_unpack_jobs(pool.ctx, (int)type, &job, 1, pool.d_arena, d_out), "adac_unpack_jobs");
-	AdacCheck(adac_memcpy_d2h(pool.ctx, target, d_out, bytes), "adac_memcpy_d2h");
-}
-
-void SuccinctUncompactFromDevice(ColumnSegment &segment) {
-	auto &state = (SuccinctSegmentState &)*segment.GetSegmentState();
-	if (state.packed_on_device) {
-		state.staged.resize(segment.SegmentSize());
-		if (segment.count) {
-			SuccinctDecodeRows(state, segment.type.InternalType(), segment.type_size, 0, segment.count, state.staged.data());
-		}
-		state.pool.Free(state.desc.word_off, state.arena_words); // the block returns to the pool's free list
-		state.packed_on_device = false;
+//! column_segment.cpp:385 — BitCompressFromUncompressed (adaptive mode): the rows of an UNCOMPRESSED transient segment
+//! move out of its block into a mirror segment, which packs them under the zero-extended rule
+//! (column_segment.cpp:390-420: the mirror database was created with the adaptive flag, so its segments start
+//! uncompressed and Compact() is that rule).  The caller stores the returned state in segment_state and swaps
+//! `function` to SUCCINCT under bit_compression_lock, as column_segment.cpp:451-455 does.
+unique_ptr<CompressedSegmentState> SuccinctAdoptUncompressed(ColumnSegment &segment) {
+	auto state = SuccinctCreateState(segment);
+	adach_segment *handle = ((SuccinctSegmentState &)*state).handle;
+	auto &buffer_manager = BufferManager::GetBufferManager(segment.db);
+	auto pinned = buffer_manager.Pin(segment.block);
+	idx_t count = segment.count;
+	int64_t copied = adach_segment_append(handle, pinned.Ptr(), nullptr, nullptr, 0, count);
+	if (copied != (int64_t)count) {
+		throw InternalException(string("adacodec: adopting an uncompressed segment: ") + adach_last_error());
 	}
-	segment.SetBitUncompressed();
+	AdachCheck(adach_segment_compact(handle), "adach_segment_compact");
+	return state;
+}
+
+//! column_segment.cpp:458 — UncompressSuccinct: expand on the device, bring the rows back into `target` (the freshly
+//! allocated block of column_segment.cpp:461-472).  The caller swaps `function` to UNCOMPRESSED and sets
+//! force_reinitializing_scan_state under bit_compression_lock (column_segment.cpp:494-503); segments that were
+//! appended through the succinct slots keep their state (the mirror serves them unpacked).
+void SuccinctRestoreUncompressed(ColumnSegment &segment, data_ptr_t target) {
+	adach_segment *handle = Handle(segment);
+	AdachCheck(adach_segment_uncompact(handle), "adach_segment_uncompact");
+	if (target && segment.count > 0) {
+		AdachCheck(adach_segment_scan(handle, segment.start, segment.count, target, 0, 1), "adach_segment_scan");
+	}
+	SuccinctSyncMembers(segment);
+}
+
+//! column_segment.cpp:204-222 — GetDataSize / SuccinctSize: sdsl::size_in_bytes(succinct_vec) of the current form
+idx_t SuccinctDataSize(ColumnSegment &segment) {
+	return adach_segment_data_size(Handle(segment));
 }
 
 //===--------------------------------------------------------------------===//
-// Scan (succinct.cpp:123-144, 232-240) and fetch (succinct.cpp:244-260, intended semantics)
+// Scan (succinct.cpp:123-144, 232-240) and fetch (succinct.cpp:244-260, intended semantics).
+// init_scan returns the state that lives in ColumnScanState::scan_state from one scan_vector call to the next
+// (ColumnData::ScanVector, column_data.cpp:92-139): the mirror pins the segment's decoded block in it — decoded once
+// per segment, together with the next segments of the column, ahead of the consumer — so a 2048-row call is a memcpy
+// out of page-locked memory and no call goes to the device.
 //===--------------------------------------------------------------------===//
-struct SuccinctScanState : public SegmentScanState {};
+struct SuccinctScanState : public SegmentScanState {
+	SuccinctScanState() : state(adach_scan_state_create()) {
+		if (!state) {
+			throw InternalException("adacodec: adach_scan_state_create");
+		}
+	}
+	~SuccinctScanState() override {
+		adach_scan_state_destroy(state); // releases the pin
+	}
+	adach_scan_state *state;
+};
 
 static unique_ptr<SegmentScanState> SuccinctInitScan(ColumnSegment &segment) {
-	return make_unique<SuccinctScanState>();
-}
-
-static void SuccinctReadRows(ColumnSegment &segment, idx_t start, idx_t count, data_ptr_t target) {
-	auto &state = (SuccinctSegmentState &)*segment.GetSegmentState();
-	if (!state.packed_on_device) {
-		memcpy(target, state.staged.data() + start * segment.type_size, count * segment.type_size);
-		return;
+	adach_segment *handle = Handle(segment);
+	// SegmentBase::next as the mirror's decode-ahead hint: the following segment of the column, once it exists
+	auto next = (ColumnSegment *)segment.Next();
+	if (next && next->function->type == CompressionType::COMPRESSION_SUCCINCT && next->GetSegmentState()) {
+		AdachCheck(adach_segment_set_next(handle, Handle(*next)), "adach_segment_set_next");
 	}
-	// (the host mirror serves this call from its decoded-segment cache: see csrc/host/succinct_host.cpp, PinDecoded)
-	SuccinctDecodeRows(state, segment.type.InternalType(), segment.type_size, start, count, target);
+	auto result = make_unique<SuccinctScanState>();
+	AdachCheck(adach_segment_init_scan(handle, result->state), "adach_segment_init_scan");
+	return move(result);
 }
 
 template <class T>
 static void SuccinctScanPartial(ColumnSegment &segment, ColumnScanState &state, idx_t scan_count, Vector &result,
                                 idx_t result_offset) {
-	auto start = segment.GetRelativeIndex(state.row_index);
+	auto &scan_state = (SuccinctScanState &)*state.scan_state;
 	result.SetVectorType(VectorType::FLAT_VECTOR);
-	SuccinctReadRows(segment, start, scan_count, FlatVector::GetData(result) + result_offset * sizeof(T));
+	AdachCheck(adach_segment_scan_with(Handle(segment), scan_state.state, state.row_index, scan_count,
+	                                   FlatVector::GetData(result), result_offset, 0),
+	           "adach_segment_scan_with");
 }
 
 template <class T>
@@ -431,10 +307,14 @@ static void SuccinctScan(ColumnSegment &segment, ColumnScanState &state, idx_t s
 	SuccinctScanPartial<T>(segment, state, scan_count, result, 0);
 }
 
+//! the mirror reads under the segment's lock, from the decoded block when the segment has one (no device call),
+//! else with one range decode; ColumnSegment::FetchRow hands over row_id - start (column_segment.cpp:193-195)
 template <class T>
 static void SuccinctFetchRow(ColumnSegment &segment, ColumnFetchState &state, row_t row_id, Vector &result,
                              idx_t result_idx) {
-	SuccinctReadRows(segment, (idx_t)row_id, 1, FlatVector::GetData(result) + result_idx * sizeof(T));
+	AdachCheck(adach_segment_fetch_row(Handle(segment), row_id + (row_t)segment.start, FlatVector::GetData(result),
+	                                   result_idx),
+	           "adach_segment_fetch_row");
 }
 
 //===--------------------------------------------------------------------===//
@@ -474,7 +354,7 @@ CompressionFunction SuccinctFun::GetFunction(PhysicalType data_type) {
 }
 
 bool SuccinctFun::TypeIsSupported(PhysicalType type) {
-	return adac_type_is_supported((int)type) != 0; // duckdb::PhysicalType codes are adac_type codes
+	return adach_type_is_supported((int)type) != 0; // duckdb::PhysicalType codes are the mirror's type codes
 }
 
 } // namespace duckdb

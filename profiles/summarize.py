@@ -41,9 +41,10 @@ def short(name):
             extra = ""
             if k == "k_scan_agg":  # k_scan_agg<U, OP, V>: OP 0 sum, 1 count(range), 2 probe, 3 select bitmap
                 import re
-                m = re.search(r"k_scan_agg<[^,]+, (\d), (true|false)>", name)
+                m = re.search(r"k_scan_agg<[^,]+, (\d), (true|false)(?:, (true|false))?>", name)
                 op = {"0": "sum", "1": "count", "2": "probe", "3": "select"}.get(m.group(1), "?") if m else "?"
-                extra = "," + op + (",valid" if m and m.group(2) == "true" else "")
+                extra = "," + op + (",valid" if m and m.group(2) == "true" else "") + \
+                    (",narrow" if m and m.group(3) == "true" else "")
             if k == "k_unpack" and ", true>" in name:
                 extra = ",range"
             return "%s<%s%s>" % (k, t, extra) if t else k
@@ -92,13 +93,15 @@ def main():
     json.dump(summary, open(os.path.join(here, "%s_pmc_summary.json" % tag), "w"), indent=1, sort_keys=True)
     if "k_unpack<u64>" in summary["kernels"]:
         k = summary["kernels"]["k_unpack<u64>"]
-        import hashlib
-        h = hashlib.sha256()
-        for f in ("adac_kernels.hip", "adac_internal.h"):  # the same hash bench.py computes (kernel_source_sha256)
-            h.update(open(os.path.join(here, "..", "duckdb-adaptive-compression_amd", "csrc", f), "rb").read())
-        json.dump({"round": tag, "rows": int(rows), "kernel": "k_unpack<u64>", "kernel_source_sha256": h.hexdigest(),
+        import importlib
+        sys.path.insert(0, os.path.join(here, ".."))
+        sha = importlib.import_module("duckdb-adaptive-compression_amd").kernel_source_sha256()  # bench.py's hash
+        per_kernel = {n: {f: summary["kernels"][n][f] for f in ("hbm_bytes", "hbm_read_bytes", "hbm_write_bytes")}
+                      for n in ("k_unpack<u64>", "k_scan_agg<u64,sum>", "k_scan_agg<u64,select>", "k_encode_1p<u64>")
+                      if n in summary["kernels"]}
+        json.dump({"round": tag, "rows": int(rows), "kernel": "k_unpack<u64>", "kernel_source_sha256": sha,
                    "hbm_bytes_per_launch": k["hbm_bytes"], "hbm_read_bytes": k["hbm_read_bytes"],
-                   "hbm_write_bytes": k["hbm_write_bytes"],
+                   "hbm_write_bytes": k["hbm_write_bytes"], "kernels": per_kernel,
                    "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; KiB*1024; "
                              "FETCH_SIZE doubled (gfx950 16 B/lane streaming-read correction)"},
                   open(os.path.join(here, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)

@@ -46,7 +46,7 @@ def test_two_rank_gloo_plumbing(adac):
     lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout.decode()  # exactly one JSON line, from rank 0
     r = json.loads(lines[0])
-    assert r["n_gpus"] == 2 and r["data"] == "plumbing-only" and r["value"] is None
+    assert r["n_gpus"] == 2 and r["data"] == "plumbing-only" and r["value"] is None and r["scaling"] == "weak"
     assert r["total_rows"] == 2 * 500000          # --rows is per GPU: the global column has rows x world rows
     assert abs(r["max_elapsed"] - 0.002) < 1e-9   # MAX over ranks, not rank 0's own 0.001
     counts = adac.appender_segment_counts(2 * 500000, 8)   # ONE column of 1 M rows, not two of 500 k
@@ -55,6 +55,32 @@ def test_two_rank_gloo_plumbing(adac):
     assert r["rank0_rows"] == int(counts[:len(counts) // 2].sum())
     # the ranks' slices are disjoint, cover the column and hold the global column's values
     assert r["checksum_of_checksums"] == r["column_checksum"]
+
+
+def test_eight_rank_gloo_rehearsal_of_the_c4_launch_line(adac):
+    """The driver's own N = 8 command (python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 ... bench.py
+    --gpus 8) with C4's flag (--total-rows: ONE column cut eight ways = strong scaling), at reduced rows and without
+    any device work: rendezvous of eight ranks, the eight-way partition, the per-rank block of the JSON line."""
+    adac.build()
+    total = 2_400_000
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "8", "--total-rows", str(total), "--plumbing-only",
+           "--backend", "gloo"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout.decode()
+    r = json.loads(lines[0])
+    counts = adac.appender_segment_counts(total, 8)
+    assert r["n_gpus"] == 8 and r["scaling"] == "strong" and r["total_rows"] == total
+    assert r["total_segments"] == len(counts) and r["checksum_of_checksums"] == r["column_checksum"]
+    pr = r["per_rank"]
+    assert [p["rank"] for p in pr] == list(range(8)) and [p["device"] for p in pr] == list(range(8))
+    assert sum(p["rows"] for p in pr) == total and sum(p["segments"] for p in pr) == len(counts)
+    assert max(p["segments"] for p in pr) - min(p["segments"] for p in pr) <= 1   # balanced to within one segment
+    assert abs(r["max_elapsed"] - 0.008) < 1e-9
 
 
 def test_column_shards_are_slices_of_one_column(adac):
