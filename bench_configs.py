@@ -324,6 +324,15 @@ def q1_packed(adac, n=59_986_052):
         for _ in range(reps):
             lay.scan_group_sum(words, klay, kwords, 6, d_sums, d_cnts)
         ms = ctx.timer_stop() / reps
+        # the same aggregate through the staged-LDS kernel alone (round 2's form), for the record
+        adac.set_tuning("group_sum_rw", 0)
+        lay.scan_group_sum(words, klay, kwords, 6, d_sums, d_cnts)
+        ctx.timer_start()
+        for _ in range(reps):
+            lay.scan_group_sum(words, klay, kwords, 6, d_sums, d_cnts)
+        ms_lds = ctx.timer_stop() / reps
+        assert d_sums.download(np.uint64, 7).tolist() == got_s and d_cnts.download(np.uint64, 7).tolist() == got_c
+        adac.set_tuning("group_sum_rw", 1)
         d_out = ctx.alloc(n * 4 + 64)
         lay.unpack(words, d_out)
         ctx.timer_start()
@@ -335,7 +344,7 @@ def q1_packed(adac, n=59_986_052):
         total_bytes += nbytes + kbytes
         out["columns"].append({"column": name, "widths": widths, "packed_bytes": nbytes, "group_sum_ms": ms,
                                "rows_per_s": n / (ms * 1e-3), "packed_read_GBps": (nbytes + kbytes) / (ms * 1e-3) / 1e9,
-                               "decode_only_ms": ms_dec})
+                               "staged_lds_kernel_ms": ms_lds, "decode_only_ms": ms_dec})
         del lay, words
     out["q1_three_aggregates_ms"] = total_ms
     out["q1_rows_per_s"] = n / (total_ms * 1e-3)

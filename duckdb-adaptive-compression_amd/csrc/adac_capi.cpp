@@ -86,6 +86,7 @@ struct adac_layout {
 	void *d_sel_edges = nullptr;     // shared-word records of the selection scan (two per scan group)
 	uint64_t sel_edges_groups = 0;   // ... sized for this many groups
 	void *d_group_partial = nullptr; // per-workgroup partials of adac_scan_group_sum (allocated on first use)
+	uint32_t group_calls = 0;        // ... and how often it ran: its hand-over word alternates between two slots
 };
 
 static adac_status descs_changed(adac_layout *l);
@@ -338,6 +339,7 @@ extern "C" int adac_set_tuning(const char *name, int value) {
 	else if (n == "encode_stamps") adac::g_tuning.encode_stamps = value;
 	else if (n == "encode_placement") adac::g_tuning.encode_placement = value;
 	else if (n == "group_sum_wide") adac::g_tuning.group_sum_wide = value;
+	else if (n == "group_sum_rw") adac::g_tuning.group_sum_rw = value;
 	else if (n == "templated_scan") adac::g_tuning.templated_scan = value;
 	else if (n == "scan_tiles_per_wg" && value >= 0) adac::g_tuning.scan_tiles_per_wg = value; // 0 = by type
 	else if (n == "blocks_per_cu" && value > 0) adac::g_tuning.blocks_per_cu = value;
@@ -980,10 +982,16 @@ extern "C" adac_status adac_scan_group_sum(adac_layout *values, const uint64_t *
 	if (values->total_values && (!d_value_words || !d_key_words)) return ADAC_ERR_INVALID_ARGUMENT;
 	if (!aligned16(d_value_words) || !aligned16(d_key_words)) return ADAC_ERR_INVALID_ARGUMENT;
 	ADAC_HIP(hipSetDevice(values->ctx->device));
-	if (!values->d_group_partial) ADAC_HIP(hipMalloc(&values->d_group_partial, adac::group_sum_partial_bytes()));
+	if (!values->d_group_partial) {
+		ADAC_HIP(hipMalloc(&values->d_group_partial, adac::group_sum_partial_bytes()));
+		ADAC_HIP(hipMemsetAsync(values->d_group_partial, 0, adac::group_sum_partial_bytes(), values->ctx->stream));
+	}
+	adac_status gst = ensure_scan_groups(values); // the register-walk kernel's work items
+	if (gst != ADAC_OK) return gst;
 	ADAC_HIP(adac::launch_group_sum(values->ctx->stream, values->type_size, values->is_signed, keys->type_size,
-	                                values->d_descs, values->d_tiles, values->ntiles, d_value_words, keys->d_descs,
-	                                d_key_words, ngroups, values->d_group_partial, d_sums, d_counts));
+	                                values->d_descs, values->d_tiles, values->ntiles, values->d_groups, values->ngroups,
+	                                d_value_words, keys->d_descs, d_key_words, ngroups, values->d_group_partial,
+	                                values->group_calls++, d_sums, d_counts));
 	return ADAC_OK;
 }
 
@@ -1013,7 +1021,10 @@ static adac_status scan_range(adac_layout *l, const uint64_t *d_words, const uin
 	// (12.5 MB at C2) and no global atomics.  Value spaces with gaps between segments, and the empty range, take the
 	// full memset and atomicOr.
 	// (A/B: sel_debug 5 takes the memset + atomicOr form on a dense value space too)
-	const bool edges_only = want_bitmap && l->dense_values && bhi >= blo && l->ntiles && adac::g_tuning.sel_debug != 5;
+	// (the diagnostic forms that skip the write-out — sel_debug 1, 2 — leave no records: the merge kernel must not run
+	// over them, it would store through uninitialised word indices)
+	const bool edges_only = want_bitmap && l->dense_values && bhi >= blo && l->ntiles &&
+	                        (adac::g_tuning.sel_debug == 0 || adac::g_tuning.sel_debug == 6);
 	if (want_bitmap && l->value_span && !edges_only) {
 		ADAC_HIP(hipMemsetAsync(d_bitmap, 0, ((l->value_span + 63) / 64) * sizeof(uint64_t), l->ctx->stream));
 	}

@@ -72,6 +72,7 @@ struct Tuning {
 	int persistent_unpack = 0;  // measured 5-15 % slower than one tile per workgroup (profiles/r01_ab_*.json)
 	int single_pass_encode = 1; // A/B: 0 = analyze + plan + pack as three kernels (the raw column is read twice)
 	int group_sum_wide = 0;     // A/B: adac_scan_group_sum always in 64-bit arithmetic
+	int group_sum_rw = 1;       // A/B: 0 = adac_scan_group_sum without the register-walk kernel (k_group_sum only)
 	int encode_placement = 0;   // single-pass encode: 0 = arena order is segment order (look-back), 1 = order of completion
 	int encode_stamps = 0;      // diagnostic: phase time stamps of the single-pass encode (adac_debug_encode_stamps)
 	int grouped_repack = 1;     // A/B: 0 = one tile per workgroup with the 16 KiB row image (the first version)
@@ -113,7 +114,7 @@ hipError_t launch_repack(hipStream_t s, uint32_t type_size, uint64_t null_bits, 
 // single-pass encode (adac_encode_1p.inl): every segment must fit sixteen 16-byte chunks per thread of a 1024-thread
 // workgroup, counted from the 16-byte boundary at or before its first element
 constexpr uint64_t kEncodeOnePassBytes = 16ull * 1024 * 16;
-// 64-bit words of device scratch the single-pass encode needs for nseg segments (look-back words, ticket)
+// 64-bit words of device scratch the single-pass encode needs for nseg segments (look-back words, ticket, cursor)
 inline uint64_t encode_1p_state_words(uint64_t nseg) { return nseg + 2; }
 hipError_t read_encode_stamps(void *host, uint64_t bytes);
 // grouped SUM / COUNT over two packed columns of one table (adac_group_sum.inl)
@@ -121,8 +122,9 @@ uint64_t group_sum_partial_bytes();
 uint32_t group_sum_max_groups();
 hipError_t launch_group_sum(hipStream_t s, uint32_t v_type_size, bool v_signed, uint32_t k_type_size,
                             const adac_segment_desc *d_vdescs, const TileRef *d_vtiles, uint64_t ntiles,
-                            const uint64_t *d_vwords, const adac_segment_desc *d_kdescs, const uint64_t *d_kwords,
-                            uint32_t ngroups, void *d_partial, uint64_t *d_sums, uint64_t *d_counts);
+                            const ScanGroup *d_vgroups, uint64_t nvgroups, const uint64_t *d_vwords,
+                            const adac_segment_desc *d_kdescs, const uint64_t *d_kwords, uint32_t ngroups, void *d_partial,
+                            uint32_t call_parity, uint64_t *d_sums, uint64_t *d_counts);
 hipError_t launch_encode_1p(hipStream_t s, uint32_t type_size, bool sign_extend, uint64_t null_bits, int rule,
                             int pad_to_byte, adac_segment_desc *d_descs, uint64_t nseg, const void *d_vals,
                             const uint64_t *d_validity, uint64_t *d_minmax, void *d_scan_state, uint64_t *d_words);

@@ -71,8 +71,14 @@ __device__ __forceinline__ uint64_t wave_sum(uint64_t v) {
 
 // A descriptor at a wave-uniform address through the scalar unit: read as eight dwords (s_load_dwordx8) and taken
 // apart with scalar shifts.  Read field by field, the byte-sized members (width, flags) come through VECTOR loads —
-// gfx9 has no sub-dword scalar load — each behind its own s_waitcnt: one more memory round trip at the start of every
-// workgroup, before the first data load can be issued.
+// gfx9 has no sub-dword scalar load — each behind its own s_waitcnt.
+// Used ONLY where the width decides a branch before anything else can be issued (the fused scans' work items: the
+// narrow-width test made the vector load a second round trip at every workgroup start, 3 - 5 % of a scan; the grouped
+// scan's eligibility test).  NOT used by the tile kernels (k_unpack, k_analyze, k_pack, k_gather ...): there the
+// field-by-field form — three scalar loads and the 2-byte vector load in flight together — is the faster one; with
+// this helper in resolve_tile the decode of u64 at w = 8 ran 568 instead of 660 GB/s of packed bytes and every other
+// decode 3 - 10 % slower, same box, same ISA after the first twenty instructions (profiles/r03_scan_split_ab.json,
+// "tile_descriptor_loads").
 __device__ __forceinline__ adac_segment_desc load_desc(const adac_segment_desc *__restrict__ p) {
 	static_assert(sizeof(adac_segment_desc) == 32, "record layout");
 	const uint32_t *__restrict__ q = reinterpret_cast<const uint32_t *>(p);
@@ -106,7 +112,7 @@ __device__ __forceinline__ TileCtx resolve_tile(const adac_segment_desc *__restr
 	const TileRef r = tiles[blockIdx.x];
 	t.seg = r.seg;
 	t.first = r.first;
-	t.d = load_desc(descs + r.seg);
+	t.d = descs[r.seg]; // field by field on purpose: see load_desc
 	const uint32_t left = t.d.count - r.first;
 	t.n = left < (uint32_t)TILE ? left : (uint32_t)TILE;
 	t.elem0 = t.d.val_off + r.first;
@@ -323,7 +329,7 @@ __global__ __launch_bounds__(kWorkgroup) void k_unpack(const adac_segment_desc *
 	uint32_t first, n;
 	uint64_t elem0;
 	if (RANGE) {
-		d = load_desc(descs + range.seg);
+		d = descs[range.seg];
 		const uint32_t done = blockIdx.x * (uint32_t)TILE;
 		first = range.start + done;
 		const uint32_t left = range.count - done;
@@ -476,6 +482,7 @@ struct SelOut {
 	uint32_t p_base;    // position of bit 0 of the image: ((val_off & 31) + first) & ~31
 	int debug;          // diagnostic (adac_set_tuning "sel_debug"): 1 = no write-out, 2 = no emit at all (results wrong)
 	SelEdge *edges;     // dense value spaces: the group's two records for the words it shares (nullptr: global atomicOr)
+	bool nt;            // A/B: non-temporal bitmap stores
 };
 
 __device__ __forceinline__ void sel_or(const SelOut &o, uint32_t p, uint32_t bits, uint32_t nbits) {
@@ -495,7 +502,11 @@ __device__ __forceinline__ void sel_write_out(const SelOut &o, uint32_t *__restr
 		const uint32_t wb = o.p_base + 32u * i;
 		uint32_t *g = seg_words32 + (wb >> 5);
 		if (wb >= p0 && wb + 32u <= p1) {
-			*g = v;
+			if (o.nt) { // A/B (sel_debug 6): the bitmap words streamed past the caches
+				__builtin_nontemporal_store(v, g);
+			} else {
+				*g = v;
+			}
 		} else if (o.edges) { // only the first and the last word of the group can be shared
 			SelEdge e;
 			e.word = (uint64_t)(g - o.bitmap32);
@@ -864,7 +875,8 @@ __global__ __launch_bounds__(kWorkgroup, NARROW ? 4 : 6) void k_scan_agg(
 	const ScanGroup g = load_scan_group(groups, gi);
 	const adac_segment_desc &d = g.d;
 	if (!NARROW && kScanHasNarrowKernel<OP, V> && scan_width_is_narrow(d.width)) return; // the narrow kernel's group
-	SelOut sel_out {sel_img, bitmap32, 0u, templated >> 1, edges ? edges + 2u * (uint64_t)gi : nullptr};
+	SelOut sel_out {sel_img, bitmap32, 0u, (templated >> 1) == 6 ? 0 : (templated >> 1),
+	                edges ? edges + 2u * (uint64_t)gi : nullptr, (templated >> 1) == 6};
 	templated &= 1;
 	const uint32_t sel_p0 = (uint32_t)(d.val_off & 31u) + g.first; // the group's positions [sel_p0, sel_p0 + n)
 	if (OP == 3) {
@@ -969,7 +981,7 @@ __device__ __forceinline__ TileJob make_job(const adac_segment_desc *__restrict_
                                             const TileRef *__restrict__ tiles, uint32_t t,
                                             const uint64_t *__restrict__ words) {
 	const TileRef r = tiles[t];
-	const adac_segment_desc d = load_desc(descs + r.seg);
+	const adac_segment_desc d = descs[r.seg];
 	TileJob j;
 	j.seg = r.seg;
 	const uint32_t left = d.count - r.first;
@@ -1387,7 +1399,7 @@ __global__ __launch_bounds__(kWorkgroup) void k_repack(const adac_segment_desc *
 	__shared__ uint4 lds[kTileBytes / 16 + 2];
 	__shared__ __attribute__((aligned(16))) U delta[TILE];
 	const TileCtx t = resolve_tile<TILE>(src_descs, tiles);
-	const adac_segment_desc dd = load_desc(dst_descs + t.seg);
+	const adac_segment_desc dd = dst_descs[t.seg];
 	const uint32_t w = dd.width;
 	const bool packed = (dd.flags & ADAC_SEG_PACKED) != 0;
 	const U sub = (U)((packed && dd.min != ADAC_NO_MIN) ? dd.min : 0ull); // column_segment.cpp:371-373
@@ -1754,7 +1766,7 @@ __global__ __launch_bounds__(kWorkgroup) void k_repack_g(const ScanGroup *__rest
 	__shared__ __attribute__((aligned(16))) unsigned long long img[kImgWords];
 	const ScanGroup g = load_scan_group(src_groups, blockIdx.x);
 	const adac_segment_desc &sd = g.d;
-	const adac_segment_desc dd = load_desc(dst_descs + g.seg);
+	const adac_segment_desc dd = dst_descs[g.seg];
 	const uint32_t w_old = sd.width, w = dd.width;
 	const bool packed = (dd.flags & ADAC_SEG_PACKED) != 0;
 	const U sub = (U)((packed && dd.min != ADAC_NO_MIN) ? dd.min : 0ull); // column_segment.cpp:371-373
@@ -2079,8 +2091,8 @@ hipError_t launch_encode_1p(hipStream_t s, uint32_t type_size, bool sign_extend,
                             int pad_to_byte, adac_segment_desc *d_descs, uint64_t nseg, const void *d_vals,
                             const uint64_t *d_validity, uint64_t *d_minmax, void *d_scan_state, uint64_t *d_words) {
 	if (nseg == 0) return hipSuccess;
-	// scan_state: nseg look-back words followed by the ticket counter, all zero before the launch
-	hipError_t e = hipMemsetAsync(d_scan_state, 0, (nseg + 2) * sizeof(unsigned long long), s);
+	// scan_state: nseg look-back words followed by the ticket counter and the first-come cursor, all zero before the launch
+	hipError_t e = hipMemsetAsync(d_scan_state, 0, encode_1p_state_words(nseg) * sizeof(unsigned long long), s);
 	if (e != hipSuccess) return e;
 	// persistent: one workgroup per CU (a segment fills half a CU's register file), segments handed out by ticket
 	const uint64_t cus = device_cus();
@@ -2095,32 +2107,54 @@ hipError_t launch_encode_1p(hipStream_t s, uint32_t type_size, bool sign_extend,
 	});
 }
 
-uint64_t group_sum_partial_bytes() { return (uint64_t)kGroupMaxWorkgroups * 2u * kGroupMaxBins * sizeof(unsigned long long); }
+// the per-workgroup partials of both scan kernels + two words used in turn: the segment pairs the register-walk kernel
+// left (the buffer is cleared when it is allocated; k_group_final clears the word of the call after it)
+uint64_t group_sum_partial_bytes() { return ((uint64_t)kGroupMaxWorkgroups * 2u * kGroupMaxBins + 2u) * sizeof(unsigned long long); }
 uint32_t group_sum_max_groups() { return kGroupMaxBins - 1u; }
 
 hipError_t launch_group_sum(hipStream_t s, uint32_t v_type_size, bool v_signed, uint32_t k_type_size,
                             const adac_segment_desc *d_vdescs, const TileRef *d_vtiles, uint64_t ntiles,
-                            const uint64_t *d_vwords, const adac_segment_desc *d_kdescs, const uint64_t *d_kwords,
-                            uint32_t ngroups, void *d_partial, uint64_t *d_sums, uint64_t *d_counts) {
+                            const ScanGroup *d_vgroups, uint64_t nvgroups, const uint64_t *d_vwords,
+                            const adac_segment_desc *d_kdescs, const uint64_t *d_kwords, uint32_t ngroups, void *d_partial,
+                            uint32_t call_parity, uint64_t *d_sums, uint64_t *d_counts) {
 	GroupSumTypes ty;
 	ty.v_tmask = v_type_size >= 8 ? ~0ull : ((1ull << (8 * v_type_size)) - 1ull);
 	ty.v_sbit = v_signed ? (1ull << (8 * v_type_size - 1)) : 0ull;
 	ty.k_tmask = k_type_size >= 8 ? ~0ull : ((1ull << (8 * k_type_size)) - 1ull);
 	ty.v_tile_rows = tile_values(v_type_size);
 	ty.wide_only = g_tuning.group_sum_wide ? 1u : 0u;
-	// persistent: as many workgroups as are resident at once (seven per CU: 21 KiB of LDS each), so nobody runs a
-	// second round on a third of the chip
-	uint64_t cap = 7ull * device_cus();
-	cap = cap < kGroupMaxWorkgroups ? cap : kGroupMaxWorkgroups;
-	const uint32_t nwg = (uint32_t)(ntiles < cap ? ntiles : cap);
+	const uint32_t nbins = ngroups + 1u;
 	unsigned long long *partial = static_cast<unsigned long long *>(d_partial);
-	if (nwg) {
-		hipLaunchKernelGGL(k_group_sum, dim3(nwg), dim3(kWorkgroup), 0, s, d_vdescs, d_vtiles, (uint32_t)ntiles, d_vwords,
-		                   d_kdescs, d_kwords, ty, ngroups, partial);
+	unsigned long long *fallback = partial + (uint64_t)kGroupMaxWorkgroups * 2u * kGroupMaxBins + (call_parity & 1u);
+	unsigned long long *next_fallback = partial + (uint64_t)kGroupMaxWorkgroups * 2u * kGroupMaxBins + ((call_parity + 1u) & 1u);
+	// 1. the register-walk kernel over the value layout's scan groups (up to 8 bins; persistent, seven workgroups per CU);
+	//    it counts the segment pairs it cannot take in *fallback
+	uint32_t nwg_rw = 0;
+	const bool rw = nbins <= kGroupPrivateBins && !ty.wide_only && g_tuning.group_sum_rw && nvgroups > 0;
+	if (rw) {
+		const uint64_t cap = 7ull * device_cus();
+		nwg_rw = (uint32_t)(nvgroups < cap ? nvgroups : cap);
+		nwg_rw = nwg_rw < kGroupMaxWorkgroups / 2 ? nwg_rw : kGroupMaxWorkgroups / 2;
+		hipLaunchKernelGGL(k_group_sum_rw, dim3(nwg_rw), dim3(kWorkgroup), 0, s, d_vgroups, (uint32_t)nvgroups, d_vwords,
+		                   d_kdescs, d_kwords, ty, ngroups, partial, fallback);
 		hipError_t e = hipGetLastError();
 		if (e != hipSuccess) return e;
 	}
-	hipLaunchKernelGGL(k_group_final, dim3(ngroups + 1u), dim3(64), 0, s, partial, nwg, ngroups + 1u, d_sums, d_counts);
+	// 2. the staged-LDS kernel over the tiles: everything when the first kernel did not run, else what it left (its
+	//    workgroups leave at once when that is nothing).  Persistent: as many workgroups as are resident at once (seven
+	//    per CU: 21 KiB of LDS each), so nobody runs a second round on a third of the chip
+	uint64_t cap = 7ull * device_cus();
+	cap = cap < kGroupMaxWorkgroups / 2 ? cap : kGroupMaxWorkgroups / 2;
+	const uint32_t nwg = (uint32_t)(ntiles < cap ? ntiles : cap);
+	if (nwg) {
+		hipLaunchKernelGGL(k_group_sum, dim3(nwg), dim3(kWorkgroup), 0, s, d_vdescs, d_vtiles, (uint32_t)ntiles, d_vwords,
+		                   d_kdescs, d_kwords, ty, ngroups, partial + (uint64_t)nwg_rw * 2u * nbins,
+		                   rw ? fallback : static_cast<const unsigned long long *>(nullptr));
+		hipError_t e = hipGetLastError();
+		if (e != hipSuccess) return e;
+	}
+	hipLaunchKernelGGL(k_group_final, dim3(nbins), dim3(kWorkgroup), 0, s, partial, nwg_rw, nwg, nbins, d_sums, d_counts,
+	                   static_cast<const unsigned long long *>(fallback), next_fallback, rw ? 1 : 0);
 	return hipGetLastError();
 }
 

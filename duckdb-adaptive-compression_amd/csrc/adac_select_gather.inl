@@ -19,7 +19,7 @@ __global__ __launch_bounds__(kWorkgroup) void k_tile_popc(const adac_segment_des
 	const uint32_t t = blockIdx.x * (kWorkgroup / 64) + (threadIdx.x >> 6);
 	if (t >= ntiles) return;
 	const TileRef r = tiles[t];
-	const adac_segment_desc d = load_desc(descs + r.seg);
+	const adac_segment_desc d = descs[r.seg];
 	const uint32_t left = d.count - r.first;
 	const uint32_t n = left < TILE ? left : TILE;
 	const uint64_t e0 = d.val_off + r.first;

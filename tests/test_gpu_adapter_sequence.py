@@ -98,7 +98,7 @@ def scan_like_column_data(host, segs, total_rows, dtype, start_row=0):
 # same-sign range has a small max - min) and one mixed-sign range, whose segments keep their full-width slots
 # (8 sizeof(T) <= w, column_segment.cpp:363) and are served from the unpacked image without any decode
 @pytest.mark.parametrize("dtype,lo,hi", [(np.uint32, 0, 1 << 20), (np.int64, 1 << 40, (1 << 40) + (1 << 20)),
-                                         (np.uint8, 0, 200), (np.int16, -3000, -1), (np.int32, -1000, 1000)])
+                                         (np.uint8, 0, 100), (np.int16, -3000, -1), (np.int32, -1000, 1000)])
 def test_shim_sequence_serves_vectors_from_the_pinned_block(adac, host, dtype, lo, hi):
     dtype = np.dtype(dtype)
     rng = np.random.default_rng(5)

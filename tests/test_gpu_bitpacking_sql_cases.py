@@ -74,7 +74,8 @@ def test_device_codec_reproduces_the_reference_sql_expectations(adac, gpu_ctx, c
                 lay.unpack_range(d_blocks, si, e["offset"] - int(starts[si]), len(e["rows"]), d_r)
                 assert [int(x) for x in d_r.download(dtype, len(e["rows"]))] == e["rows"]
         # and the block images are the oracle's, byte for byte, under the forced mode too
-        comp = bp.Compressed(vals, valid, force_mode=sc.MODE_CODE[mode])
+        # (a NULL slot keeps the buffer's stale content in the reference; the device writes zero there: null_zero)
+        comp = bp.Compressed(vals, valid, force_mode=sc.MODE_CODE[mode], null_zero=True)
         assert plan.groups_by_mode() == comp.groups_by_mode() and plan.nseg == comp.nseg
         img = d_blocks.download(np.uint8, plan.nseg * plan.BLOCK_STRIDE)
         for i in range(comp.nseg):

@@ -43,7 +43,9 @@ def child(lib_path, cells, ops, steps):
         rd = int(((descs["count"].astype(np.uint64) * descs["width"] + 63) // 64 * 8).sum())
         d_res = ctx.alloc(len(counts) * 8)
         d_bm = ctx.alloc((rows + 63) // 64 * 8 + 8)
-        fns = {"sum": lambda: lay.scan_sum(d_words, d_res),
+        d_out = ctx.alloc(rows * dtype.itemsize + 64) if "decode" in ops else None
+        fns = {"decode": lambda: lay.unpack(d_words, d_out),   # GB/s of packed bytes READ, like the others
+               "sum": lambda: lay.scan_sum(d_words, d_res),
                "count": lambda: lay.scan_count_between(d_words, 0, 2 ** (w - 1), d_res),
                "select": lambda: lay.scan_select_between(d_words, 0, 2 ** (w - 1), d_bm, d_res)}
         for op in ops:
@@ -59,7 +61,7 @@ def child(lib_path, cells, ops, steps):
             got = int(d_res.download(np.uint64, len(counts)).sum(dtype=np.uint64)) if ops[-1] == "sum" else None
             if got is not None:
                 assert got == int(vals.astype(np.uint64).sum(dtype=np.uint64)), "SUM parity"
-        del d_words, d_res, d_bm, lay
+        del d_words, d_res, d_bm, d_out, lay
     print(json.dumps(res))
 
 

@@ -2,7 +2,7 @@
 """Phase timeline of the single-pass encode (k_encode_1p): runs one encode with the tuning knob "encode_stamps" set and
 summarises the 100 MHz wall-clock stamps thread 0 of every workgroup recorded.
 
-usage: python3 tools/encode_stamps.py <dtype>:<width> [rows]
+usage: python3 tools/encode_stamps.py <dtype>:<width> [rows] [placement: 0 ordered look-back (default), 1 first come]
 slots (per segment): 0 its iteration starts (rows loading), 1 wave 0 consumed its rows (min/max), 2 workgroup min/max
        known + next segment prefetch issued, 3 look-back done / descriptor written, 4 last store issued, 7 hardware id
 """
@@ -25,6 +25,8 @@ def main():
     w = int(c.split(":")[1])
     rows = int(sys.argv[2]) if len(sys.argv) > 2 else 100_000_000
     parts = 1
+    placement = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    adac.set_tuning("encode_placement", placement)
     ctx = adac.Context(0)
     rng = np.random.default_rng(3)
     vals = rng.integers(0, 2 ** w, size=rows, dtype=np.uint64).astype(dtype)
@@ -49,7 +51,7 @@ def main():
     us = (t - t0) / 100.0       # 100 MHz -> microseconds
     ph = np.diff(us[live], axis=1)
     names = ["loads+minmax(wave0)", "wg reduce + prefetch issue", "width+lookback", "pack+stores issued"]
-    out = {"case": c, "rows": rows, "parts": parts, "workgroups": int(nwg), "live": int(live.sum()),
+    out = {"case": c, "rows": rows, "placement": placement, "parts": parts, "workgroups": int(nwg), "live": int(live.sum()),
            "kernel_span_us": float(us[live, 4].max() - us[:, 0].min()),
            "wg_lifetime_us": {"mean": float((us[live, 4] - us[live, 0]).mean()),
                               "p10": float(np.percentile(us[live, 4] - us[live, 0], 10)),

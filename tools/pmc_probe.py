@@ -3,7 +3,8 @@
 `rocprofv3 --pmc ...` (or --kernel-trace --stats) can be attached to exactly those kernels.
 
 usage: python3 tools/pmc_probe.py <ops> <cases> [rows] [reps]
-  ops    comma list of: unpack, sum, count, select, encode, pack, repack, analyze
+  ops    comma list of: unpack, sum, count, select, encode, pack, repack, analyze, groupsum (SUM / COUNT GROUP BY a
+         6-valued uint8 code column, the Q1 shape)
   cases  comma list of <dtype>:<width>, e.g. u64:13,u64:16,u32:8
 Prints one JSON object with the HIP-event launch times (ms) per case and op.
 """
@@ -66,6 +67,19 @@ def main():
             timed("select", lambda: lay.scan_select_between(d_words, 0, 2 ** (w - 1), d_bm, d_res))
             rec["select_read_GBps"] = rd / (rec["ms"]["select"] * 1e-3) / 1e9
             del d_bm
+        if "groupsum" in ops:
+            code = rng.choice(6, size=rows, p=[.2466, .2534, .0004, .2500, .2490, .0006]).astype(np.uint8)
+            klay = adac.Layout(ctx, np.uint8, counts)
+            d_code = ctx.upload(code)
+            d_kwords = ctx.alloc(klay.max_arena_words * 8 + 128).zero()
+            klay.encode(d_code, d_kwords)
+            ctx.sync()
+            kd = klay.get_descs()
+            krd = int(((kd["count"].astype(np.uint64) * kd["width"] + 63) // 64 * 8).sum())
+            d_gs, d_gc = ctx.alloc(7 * 8), ctx.alloc(7 * 8)
+            timed("groupsum", lambda: lay.scan_group_sum(d_words, klay, d_kwords, 6, d_gs, d_gc))
+            rec["groupsum_packed_GBps"] = (rd + krd) / (rec["ms"]["groupsum"] * 1e-3) / 1e9
+            del klay, d_code, d_kwords
         if "analyze" in ops:
             timed("analyze", lambda: lay.analyze(d_vals, None, adac.RULE_APPEND))
         if "encode" in ops:
