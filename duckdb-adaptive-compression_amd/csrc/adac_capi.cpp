@@ -707,10 +707,18 @@ extern "C" adac_status adac_pack(adac_layout *l, const void *d_vals, const uint6
 
 extern "C" adac_status adac_encode(adac_layout *l, const void *d_vals, const uint64_t *d_validity, int rule,
                                    int pad_to_byte, uint64_t *d_words) {
-	// (4- and 8-byte types: the 1- and 2-byte instantiations spill registers — 16 data chunks per thread plus the
-	// per-row temporaries of 4 .. 16 rows — and are slower than the two-pass form until they are restructured)
+	// Which form?  Measured on 400 MB-of-packed-bytes columns (profiles/r03_encode_forms.json):
+	//   8-byte types       single pass wins at every width (0.276 vs 0.363 ms at C2; 8 - 25 %);
+	//   4-byte types       single pass wins only where its output is parked (w = 8, 16); at the image-flow widths the
+	//                      ORDERED placement makes every round of segments wait for its slowest workgroup and the three
+	//                      kernels are 25 - 47 % faster (w = 13: 0.453 vs 0.589 ms) — with first-come placement the single
+	//                      pass is the fastest form everywhere (0.378 ms), so it is taken whenever that is selected;
+	//   2- / 1-byte types  three kernels (the single-pass instantiations are instruction-bound / spill:
+	//                      profiles/r03_encode_small_types.json).
+	// Knob "single_pass_encode": 0 never, 1 by this table, 2 always.
+	const bool one_pass_pays = l && (l->type_size == 8 || (l->type_size == 4 && adac::g_tuning.encode_placement == 1));
 	if (l && adac::g_tuning.single_pass_encode && l->single_pass_ok &&
-	    (l->type_size >= 4 || adac::g_tuning.single_pass_encode > 1)) {
+	    (one_pass_pays || adac::g_tuning.single_pass_encode > 1)) {
 		// one kernel, the raw column read once (adac_encode_1p.inl); same descriptors, min/max and words
 		if ((!d_vals || !d_words) && l->total_values) return ADAC_ERR_INVALID_ARGUMENT;
 		if (rule != ADAC_RULE_APPEND && rule != ADAC_RULE_RECOMPACT) return ADAC_ERR_INVALID_ARGUMENT;

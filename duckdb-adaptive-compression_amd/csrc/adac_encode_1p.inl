@@ -34,20 +34,25 @@ constexpr uint32_t kEncImageWords = 48 * 1024 / 8;     // LDS image of one stage
 constexpr int kEncPrefetch = 6;                        // rounds of the next segment prefetched into LDS (96 KiB)
 constexpr unsigned long long kScanFlagAggregate = 1ull << 62, kScanFlagPrefix = 2ull << 62, kScanValueMask = (1ull << 62) - 1;
 
-// exclusive prefix of the footprints of segments [0, seg): wave 0 of the workgroup, all 64 lanes
-__device__ __forceinline__ uint64_t lookback_exclusive(unsigned long long *state, uint32_t seg) {
+// exclusive prefix of the footprints of segments [0, seg): wave 0 of the workgroup, all 64 lanes.
+// *probe (diagnostic, encode_stamps): round trips that found everything they needed << 16 | round trips that met a
+// predecessor which had not published yet
+__device__ __forceinline__ uint64_t lookback_exclusive(unsigned long long *state, uint32_t seg, uint32_t *probe) {
 	const uint32_t lane = threadIdx.x & 63u;
 	uint64_t sum = 0;
 	int64_t hi = (int64_t)seg - 1; // nearest predecessor not yet accounted for
+	uint32_t trips = 0, waits = 0;
 	while (hi >= 0) {
 		const int64_t idx = hi - (int64_t)lane;
 		unsigned long long v = kScanFlagPrefix; // lanes before segment 0 read as "prefix 0"
 		if (idx >= 0) v = __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		const uint64_t unset = __builtin_amdgcn_ballot_w64((v >> 62) == 0ull);
 		if (unset) {
+			waits++;
 			__builtin_amdgcn_s_sleep(2); // a predecessor has not published its footprint yet
 			continue;
 		}
+		trips++;
 		const uint64_t prefixed = __builtin_amdgcn_ballot_w64((v >> 62) == 2ull);
 		// lanes are ordered nearest predecessor first: take everything up to and including the first prefix
 		const uint32_t stop = prefixed ? (uint32_t)__ffsll((unsigned long long)prefixed) - 1u : 63u;
@@ -57,6 +62,7 @@ __device__ __forceinline__ uint64_t lookback_exclusive(unsigned long long *state
 		if (prefixed) break;
 		hi -= 64;
 	}
+	*probe = (trips << 16) | (waits < 0xffffu ? waits : 0xffffu);
 	return sum;
 }
 
@@ -338,7 +344,9 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 				if (tid == 0) got = atomicAdd(scan_state + nseg + 1, (unsigned long long)footprint);
 				excl = uniform64(got);
 			} else {
-				excl = seg == 0 ? 0ull : lookback_exclusive(scan_state, seg);
+				uint32_t probe = 0;
+				excl = seg == 0 ? 0ull : lookback_exclusive(scan_state, seg, &probe);
+				if (stamps && tid == 0u && seg < kEncStampMax) g_enc_stamps[seg * kEncStampSlots + 6] = probe;
 			}
 			if (tid == 0) {
 				if (seg != 0 && !first_come) {

@@ -408,6 +408,10 @@ __device__ __forceinline__ void group_rw_key_store(const uint32_t (&d)[3], uint3
 // operand is {field, 0x1000}: no widening arithmetic, no second LDS add.  group_rw_fold turns the words into the
 // wave's totals (sum of fields + rows x frame of reference) when the quarter is done.
 constexpr uint32_t kGroupRwCountShift = 44;
+// value widths of at most 8 bits: the same in a 32-bit word (rows << 20 | sum of fields: a word takes at most
+// 2 x 16384 / 31 rows of a quarter, their fields sum to less than 2^20)
+constexpr uint32_t kGroupRwNarrowShift = 20;
+template <int W> constexpr bool kGroupRwNarrow = W <= 8;
 constexpr uint32_t kGroupRwWaveRows = 1008;                    // key rows a wave stages per round: two 8-row blocks per lane
 constexpr uint32_t kGroupRwWaveKeyBytes = kGroupRwWaveRows + 16 + 64; // + the block the round starts in + read slack
 template <int W, bool DIRECT>
@@ -427,6 +431,7 @@ __device__ __forceinline__ void group_rw_walk(uint32_t r0, uint32_t r1, uint32_t
 	const bool walker = lane < LANES;
 	const uint32_t kadd4 = plan.keys_overflow ? 0u : plan.kadd_byte * 0x01010101u;
 	unsigned char *const my_bins = reinterpret_cast<unsigned char *>(wbins + (lane & (kGroupRwCopies - 1u)));
+	unsigned char *const my_bins32 = reinterpret_cast<unsigned char *>(reinterpret_cast<uint32_t *>(wbins) + (lane & (kGroupRwCopies - 1u)));
 	uint32_t L = c0 + lane;
 	const uint32_t Lc = L < clast ? L : clast;
 	uint4 q = seg16[Lc];
@@ -512,8 +517,13 @@ __device__ __forceinline__ void group_rw_walk(uint32_t r0, uint32_t r1, uint32_t
 					key = (kn[j >> 2] >> (8 * (j & 3))) & 0xffu;
 				}
 				const uint32_t bin = key < ngroups ? key : ngroups;
-				unsigned long long *slot = reinterpret_cast<unsigned long long *>(my_bins + bin * (kGroupRwCopies * 8u));
-				atomicAdd(slot, (1ull << kGroupRwCountShift) | (unsigned long long)field_of<W>(nrm, j)); // ds_add_u64, no return
+				if (kGroupRwNarrow<W>) { // fields of at most 8 bits: rows << 20 | sum fits 32 bits, a ds_add_u32 is half the LDS work
+					uint32_t *slot = reinterpret_cast<uint32_t *>(my_bins32 + bin * (kGroupRwCopies * 4u));
+					atomicAdd(slot, (1u << kGroupRwNarrowShift) | field_of<W>(nrm, j));
+				} else {
+					unsigned long long *slot = reinterpret_cast<unsigned long long *>(my_bins + bin * (kGroupRwCopies * 8u));
+					atomicAdd(slot, (1ull << kGroupRwCountShift) | (unsigned long long)field_of<W>(nrm, j)); // ds_add_u64, no return
+				}
 			};
 			if (starting <= lim) { // every row that starts in the chunk belongs to the quarter: no per-row test
 #pragma unroll
@@ -544,15 +554,26 @@ __device__ __forceinline__ void group_rw_walk(uint32_t r0, uint32_t r1, uint32_t
 
 // The quarter is done: the wave's bin words -> its totals, and zero again.  total sum += sum of fields + rows x vadd
 // (mod 2^64).  A lane reads four words (bins (lane >> 5) + 2 k); 32 lanes add into the same total.
-__device__ __forceinline__ void group_rw_fold(unsigned long long *wbins, unsigned long long *wtot, uint64_t vadd) {
+__device__ __forceinline__ void group_rw_fold(unsigned long long *wbins, unsigned long long *wtot, uint64_t vadd,
+                                              bool narrow) {
 	const uint32_t lane = threadIdx.x & 63u;
 #pragma unroll
 	for (uint32_t k = 0; k < kGroupPrivateBins * kGroupRwCopies / 64u; k++) {
 		const uint32_t idx = lane + 64u * k;
-		const unsigned long long v = wbins[idx];
-		if (v) {
-			wbins[idx] = 0ull;
-			const uint64_t cnt = v >> kGroupRwCountShift, fields = v & ((1ull << kGroupRwCountShift) - 1ull);
+		uint64_t cnt, fields;
+		if (narrow) { // uniform: the quarter used the 32-bit words (the first half of the array)
+			uint32_t *w32 = reinterpret_cast<uint32_t *>(wbins);
+			const uint32_t v = w32[idx];
+			if (v) w32[idx] = 0u;
+			cnt = v >> kGroupRwNarrowShift;
+			fields = v & ((1u << kGroupRwNarrowShift) - 1u);
+		} else {
+			const unsigned long long v = wbins[idx];
+			if (v) wbins[idx] = 0ull;
+			cnt = v >> kGroupRwCountShift;
+			fields = v & ((1ull << kGroupRwCountShift) - 1ull);
+		}
+		if (cnt) {
 			atomicAdd(&wtot[2u * (idx / kGroupRwCopies)], (unsigned long long)(fields + cnt * vadd));
 			atomicAdd(&wtot[2u * (idx / kGroupRwCopies) + 1u], (unsigned long long)cnt);
 		}
@@ -611,7 +632,7 @@ __global__ __launch_bounds__(kWorkgroup, 7) void k_group_sum_rw(const ScanGroup 
 			default: break;
 			}
 		}
-		group_rw_fold(bins[wave], tot[wave], plan.vadd);
+		group_rw_fold(bins[wave], tot[wave], plan.vadd, g.d.width <= 8u);
 	}
 	if (skipped && tid == 0u) atomicAdd(fallback, (unsigned long long)skipped);
 	__syncthreads();

@@ -648,14 +648,16 @@ def test_unpack_jobs_layout_free_batches(adac, oracle, gpu_ctx):
             adac.unpack_jobs(gpu_ctx, dtype, bad, d_words, base)
 
 
-@pytest.mark.parametrize("dtype", [np.uint64, np.int64, np.uint32, np.int32])
+@pytest.mark.parametrize("dtype", [np.uint64, np.int64, np.uint32, np.int32, np.uint16, np.int16, np.uint8])
 def test_single_pass_encode_mixes_its_flows(adac, oracle, gpu_ctx, dtype):
     """The single-pass encode is persistent: one workgroup works through many segments and chooses per segment between
     the parked whole-dword flow (LDS parking area over the prefetch stage and the image), the staged image flow, the
     wide whole-dword flow and the unpacked copy.  Many more segments than CUs, of every size up to a full block, at
     random placements, with widths that alternate between the flows: the hand-over of the LDS pool (a parked segment
     dirties the image), of the prefetched rounds and of the early loads must never leak from one segment into the
-    next.  Compared word for word with the oracle, both rules, padded on and off, and with the three-kernel form."""
+    next.  Compared word for word with the oracle, both rules, padded on and off, and with the three-kernel form.
+    (Every type is forced through the single-pass kernel here, also those adac_encode sends to the three kernels by
+    default: profiles/r03_encode_forms.json, r03_encode_small_types.json.)"""
     dtype = np.dtype(dtype)
     tb = 8 * dtype.itemsize
     rng = np.random.default_rng(1234 + tb + (dtype.kind == "i"))
@@ -673,17 +675,25 @@ def test_single_pass_encode_mixes_its_flows(adac, oracle, gpu_ctx, dtype):
         run += int(c)
     seg_vals = [make_values(rng, dtype, int(c), flow_widths[int(rng.integers(0, len(flow_widths)))]) for c in counts]
     val_offs = np.array(offs, dtype=np.uint64)
-    for rule in (adac.RULE_APPEND, adac.RULE_RECOMPACT):
-        for padded in (False, True):
-            run_encode_decode(adac, oracle, gpu_ctx, dtype, counts, seg_vals, rule, padded, val_offs=val_offs)
-    # the three-kernel form on the same column: identical descriptors and arena
-    lay1, w1, _, d1, _ = run_encode_decode(adac, oracle, gpu_ctx, dtype, counts, seg_vals, val_offs=val_offs)
+    # knob 2 = the single-pass kernel whatever the type (by default adac_encode takes it for the 8-byte types only, and
+    # for the 4-byte ones under first-come placement: profiles/r03_encode_forms.json)
+    adac.set_tuning("single_pass_encode", 2)
+    try:
+        for rule in (adac.RULE_APPEND, adac.RULE_RECOMPACT):
+            for padded in (False, True):
+                run_encode_decode(adac, oracle, gpu_ctx, dtype, counts, seg_vals, rule, padded, val_offs=val_offs)
+        lay1, w1, _, d1, _ = run_encode_decode(adac, oracle, gpu_ctx, dtype, counts, seg_vals, val_offs=val_offs)
+    finally:
+        adac.set_tuning("single_pass_encode", 1)
+    # the three-kernel form on the same column: identical descriptors and arena; and the default choice
     adac.set_tuning("single_pass_encode", 0)
     try:
         lay3, w3, _, d3, _ = run_encode_decode(adac, oracle, gpu_ctx, dtype, counts, seg_vals, val_offs=val_offs)
     finally:
         adac.set_tuning("single_pass_encode", 1)
     assert d1.tobytes() == d3.tobytes()
+    _, _, _, dd, _ = run_encode_decode(adac, oracle, gpu_ctx, dtype, counts, seg_vals, val_offs=val_offs)
+    assert dd.tobytes() == d3.tobytes()
     # first-come placement: same widths / mins / words per segment at offsets of its own choosing
     adac.set_tuning("encode_placement", 1)
     try:

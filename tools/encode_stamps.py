@@ -60,6 +60,10 @@ def main():
            "phase_us_p90": {n: float(np.percentile(ph[:, i], 90)) for i, n in enumerate(names)}}
     out["lookback_only_us_mean"] = float(((buf[live, 5].astype(np.int64) - t[live, 2]) / 100.0).mean())
     out["barrier_after_lookback_us_mean"] = float(((t[live, 3] - buf[live, 5].astype(np.int64)) / 100.0).mean())
+    probe = buf[live, 6]
+    out["lookback_round_trips_mean"] = float((probe >> np.uint64(16)).mean())
+    out["lookback_unpublished_retries_mean"] = float((probe & np.uint64(0xffff)).mean())
+    out["lookback_unpublished_retries_p90"] = float(np.percentile((probe & np.uint64(0xffff)).astype(np.int64), 90))
     hw = buf[:, 7]
     xcc = (hw >> np.uint64(32)) & np.uint64(0xf)
     cu = (hw >> np.uint64(8)) & np.uint64(0xf)
