@@ -15,7 +15,8 @@ import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libadacodec.so")
+# ADAC_LIB: another build of the same library (same-box A/B of two builds, tools/ab_encode.py); default: in-tree
+LIB_PATH = os.environ.get("ADAC_LIB") or os.path.join(_HERE, "libadacodec.so")
 
 # adac_type == duckdb::PhysicalType codes
 UINT8, INT8, UINT16, INT16, UINT32, INT32, UINT64, INT64 = 2, 3, 4, 5, 6, 7, 8, 9

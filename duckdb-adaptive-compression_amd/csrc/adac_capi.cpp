@@ -61,6 +61,7 @@ struct adac_layout {
 	bool single_pass_ok = true; // every segment fits the single-pass encode kernel's registers
 	void *d_scan_state = nullptr; // its look-back words + ticket (allocated on first use)
 	bool dense_values = true; // segments back to back from element 0: no element index between them is unowned
+	bool has_empty_segments = false; // a segment without rows has no scan group: its result is cleared, not stored
 	std::vector<uint32_t> counts;
 	std::vector<uint64_t> val_offs;
 	adac_segment_desc *d_descs = nullptr;
@@ -83,6 +84,9 @@ struct adac_layout {
 	uint32_t *d_tile_cnt = nullptr;
 	uint64_t *d_tile_off = nullptr;
 	uint64_t *d_block_tot = nullptr;
+	// arrival cells of the fused scans (ScanGroupRef): zero between calls
+	unsigned long long *d_res_cells = nullptr;
+	uint32_t *d_edge_cells = nullptr;
 	void *d_sel_edges = nullptr;     // shared-word records of the selection scan (two per scan group)
 	uint64_t sel_edges_groups = 0;   // ... sized for this many groups
 	void *d_group_partial = nullptr; // per-workgroup partials of adac_scan_group_sum (allocated on first use)
@@ -338,6 +342,9 @@ extern "C" int adac_set_tuning(const char *name, int value) {
 	else if (n == "single_pass_encode") adac::g_tuning.single_pass_encode = value;
 	else if (n == "encode_stamps") adac::g_tuning.encode_stamps = value;
 	else if (n == "encode_placement") adac::g_tuning.encode_placement = value;
+	else if (n == "encode_publish_ahead") adac::g_tuning.encode_publish_ahead = value;
+	else if (n == "scan_cells") adac::g_tuning.scan_cells = value;
+	else if (n == "gather_compact") adac::g_tuning.gather_compact = value;
 	else if (n == "group_sum_wide") adac::g_tuning.group_sum_wide = value;
 	else if (n == "group_sum_rw") adac::g_tuning.group_sum_rw = value;
 	else if (n == "templated_scan") adac::g_tuning.templated_scan = value;
@@ -516,6 +523,7 @@ extern "C" adac_status adac_layout_create(adac_ctx *c, int type, const uint32_t 
 			l->single_pass_ok = false;
 		}
 		run = off + counts[s];
+		if (counts[s] == 0) l->has_empty_segments = true;
 		if (off + counts[s] > l->value_span) l->value_span = off + counts[s];
 		l->total_values += counts[s];
 		adac_segment_desc &d = descs[s];
@@ -574,6 +582,8 @@ extern "C" void adac_layout_destroy(adac_layout *l) {
 	if (l->d_scan_state) (void)hipFree(l->d_scan_state);
 	if (l->d_group_partial) (void)hipFree(l->d_group_partial);
 	if (l->d_sel_edges) (void)hipFree(l->d_sel_edges);
+	if (l->d_res_cells) (void)hipFree(l->d_res_cells);
+	if (l->d_edge_cells) (void)hipFree(l->d_edge_cells);
 	adac_ctx *c = l->ctx;
 	delete l;
 	ctx_release(c);
@@ -648,7 +658,9 @@ static adac_status scan_group_list(adac_layout *l, adac::ScanGroupList *gl) {
 		ADAC_HIP(hipEventSynchronize(l->narrow_ev));
 		l->narrow_pending = false;
 	}
-	*gl = adac::ScanGroupList {l->d_groups, l->ngroups, l->d_narrow_idx, *l->h_narrow_count};
+	const bool cells = adac::g_tuning.scan_cells != 0;
+	*gl = adac::ScanGroupList {l->d_groups, l->ngroups, l->d_narrow_idx, *l->h_narrow_count,
+	                           cells ? l->d_res_cells : nullptr, cells ? l->d_edge_cells : nullptr};
 	return ADAC_OK;
 }
 
@@ -925,16 +937,58 @@ static adac_status ensure_scan_groups(adac_layout *l) {
 			if (ntiles == 0) continue;
 			const uint64_t ngroups = (ntiles + (uint64_t)per - 1) / (uint64_t)per;
 			const uint64_t rows_per_group = ((ntiles + ngroups - 1) / ngroups) * tile;
+			const size_t seg_first = refs.size();
 			for (uint64_t first = 0; first < l->counts[s]; first += rows_per_group) {
 				const uint64_t left = l->counts[s] - first;
-				refs.push_back(adac::ScanGroupRef {(uint32_t)s, (uint32_t)first,
-				                                   (uint32_t)(left < rows_per_group ? left : rows_per_group), 0u});
+				adac::ScanGroupRef r {};
+				r.seg = (uint32_t)s;
+				r.first = (uint32_t)first;
+				r.rows = (uint32_t)(left < rows_per_group ? left : rows_per_group);
+				refs.push_back(r);
+			}
+			for (size_t g = seg_first; g < refs.size(); g++) refs[g].seg_groups = (uint32_t)(refs.size() - seg_first);
+		}
+		if (refs.size() >= 0x7fffffffull) return ADAC_ERR_INVALID_ARGUMENT;
+		if (l->dense_values) {
+			// Bitmap words that groups cover in part (sel_write_out's test: word 0 of a group unless the group starts on a
+			// word boundary and fills it; its last word, if it has more than one, unless it ends on a boundary).  The
+			// groups are in element order, so the arrivals at one word are neighbours in this list: a run of equal words
+			// shares the cell named after its first arrival and expects as many arrivals as the run is long.
+			struct Arrival {
+				uint64_t word;
+				uint32_t group, which;
+			};
+			std::vector<Arrival> arr;
+			for (size_t g = 0; g < refs.size(); g++) {
+				const uint64_t p0 = l->val_offs[refs[g].seg] + refs[g].first, p1 = p0 + refs[g].rows;
+				const uint64_t nwords = ((p1 + 31) >> 5) - (p0 >> 5);
+				if (!((p0 & 31) == 0 && p0 + 32 <= p1)) arr.push_back(Arrival {p0 >> 5, (uint32_t)g, 0u});
+				if (nwords > 1 && (p1 & 31) != 0) arr.push_back(Arrival {(p1 - 1) >> 5, (uint32_t)g, 1u});
+			}
+			for (size_t a = 0; a < arr.size();) {
+				size_t b = a;
+				while (b < arr.size() && arr[b].word == arr[a].word) b++;
+				const uint32_t cell = 2u * arr[a].group + arr[a].which;
+				const uint16_t n = (uint16_t)(b - a); // a word holds 32 rows and every group at least one: n <= 32
+				for (size_t i = a; i < b; i++) {
+					adac::ScanGroupRef &r = refs[arr[i].group];
+					if (arr[i].which == 0) {
+						r.cell_first = cell;
+						r.n_first = n;
+					} else {
+						r.cell_last = cell;
+						r.n_last = n;
+					}
+				}
+				a = b;
 			}
 		}
 		if (refs.size() >= 0x7fffffffull) return ADAC_ERR_INVALID_ARGUMENT;
 		if (l->d_group_refs) (void)hipFree(l->d_group_refs);
 		if (l->d_groups) (void)hipFree(l->d_groups);
 		if (l->d_narrow_idx) (void)hipFree(l->d_narrow_idx);
+		if (l->d_edge_cells) (void)hipFree(l->d_edge_cells);
+		l->d_edge_cells = nullptr;
 		l->d_group_refs = nullptr;
 		l->d_groups = nullptr;
 		l->d_narrow_idx = nullptr;
@@ -942,6 +996,12 @@ static adac_status ensure_scan_groups(adac_layout *l) {
 		ADAC_HIP(hipMalloc((void **)&l->d_group_refs, (refs.size() ? refs.size() : 1) * sizeof(adac::ScanGroupRef)));
 		ADAC_HIP(hipMalloc((void **)&l->d_groups, (refs.size() ? refs.size() : 1) * sizeof(adac::ScanGroup)));
 		ADAC_HIP(hipMalloc((void **)&l->d_narrow_idx, (refs.size() ? refs.size() : 1) * sizeof(uint32_t)));
+		ADAC_HIP(hipMalloc((void **)&l->d_edge_cells, adac::scan_edge_cell_bytes(refs.size())));
+		ADAC_HIP(hipMemsetAsync(l->d_edge_cells, 0, adac::scan_edge_cell_bytes(refs.size()), l->ctx->stream));
+		if (!l->d_res_cells) {
+			ADAC_HIP(hipMalloc((void **)&l->d_res_cells, adac::scan_res_cell_bytes(l->nseg)));
+			ADAC_HIP(hipMemsetAsync(l->d_res_cells, 0, adac::scan_res_cell_bytes(l->nseg), l->ctx->stream));
+		}
 		if (!l->d_narrow_count) {
 			ADAC_HIP(hipMalloc((void **)&l->d_narrow_count, sizeof(uint32_t)));
 			ADAC_HIP(hipHostMalloc((void **)&l->h_narrow_count, sizeof(uint32_t), hipHostMallocDefault));
@@ -971,11 +1031,15 @@ extern "C" adac_status adac_scan_sum_valid(adac_layout *l, const uint64_t *d_wor
 	if (!l || (l->nseg && !d_sums) || (l->total_values && !d_words)) return ADAC_ERR_INVALID_ARGUMENT;
 	if (!aligned16(d_words)) return ADAC_ERR_INVALID_ARGUMENT;
 	ADAC_HIP(hipSetDevice(l->ctx->device));
-	if (l->nseg) ADAC_HIP(hipMemsetAsync(d_sums, 0, l->nseg * sizeof(uint64_t), l->ctx->stream));
 	const uint64_t sbit = l->is_signed ? (1ull << (8 * l->type_size - 1)) : 0ull;
 	adac::ScanGroupList gl;
 	adac_status gst = scan_group_list(l, &gl);
 	if (gst != ADAC_OK) return gst;
+	// (with arrival cells every segment's total is STORED by the last of its groups: nothing to clear; a segment
+	// without rows has no group and is cleared here)
+	if (l->nseg && (!gl.d_res_cells || l->has_empty_segments)) {
+		ADAC_HIP(hipMemsetAsync(d_sums, 0, l->nseg * sizeof(uint64_t), l->ctx->stream));
+	}
 	ADAC_HIP(adac::launch_scan_sum(l->ctx->stream, l->type_size, gl, d_words, d_validity, sbit, d_sums));
 	return ADAC_OK;
 }
@@ -1017,7 +1081,6 @@ static adac_status scan_range(adac_layout *l, const uint64_t *d_words, const uin
 	if (want_bitmap && ((l->value_span && !d_bitmap) || d_bitmap == d_validity)) return ADAC_ERR_INVALID_ARGUMENT;
 	if (!aligned16(d_words)) return ADAC_ERR_INVALID_ARGUMENT;
 	ADAC_HIP(hipSetDevice(l->ctx->device));
-	if (l->nseg) ADAC_HIP(hipMemsetAsync(d_counts, 0, l->nseg * sizeof(uint64_t), l->ctx->stream));
 	// order-preserving map of T onto unsigned numbers: flip the sign bit of the signed types
 	const uint32_t bits = 8 * l->type_size;
 	const uint64_t umask = bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);
@@ -1032,15 +1095,25 @@ static adac_status scan_range(adac_layout *l, const uint64_t *d_words, const uin
 	// (the diagnostic forms that skip the write-out — sel_debug 1, 2 — leave no records: the merge kernel must not run
 	// over them, it would store through uninitialised word indices)
 	const bool edges_only = want_bitmap && l->dense_values && bhi >= blo && l->ntiles &&
-	                        (adac::g_tuning.sel_debug == 0 || adac::g_tuning.sel_debug == 6);
+	                        (adac::g_tuning.sel_debug == 0 || adac::g_tuning.sel_debug >= 6);
 	if (want_bitmap && l->value_span && !edges_only) {
 		ADAC_HIP(hipMemsetAsync(d_bitmap, 0, ((l->value_span + 63) / 64) * sizeof(uint64_t), l->ctx->stream));
 	}
-	if (bhi < blo) return ADAC_OK; // empty range: all counts (and bits) stay zero
+	if (bhi < blo) { // empty range: all counts (and bits) are zero
+		if (l->nseg) ADAC_HIP(hipMemsetAsync(d_counts, 0, l->nseg * sizeof(uint64_t), l->ctx->stream));
+		return ADAC_OK;
+	}
 	adac::ScanGroupList gl;
 	adac_status gst = scan_group_list(l, &gl);
 	if (gst != ADAC_OK) return gst;
-	if (edges_only && l->sel_edges_groups < l->ngroups) {
+	// (with arrival cells every segment's count is STORED by the last of its groups: nothing to clear)
+	if (l->nseg && (!gl.d_res_cells || l->has_empty_segments)) {
+		ADAC_HIP(hipMemsetAsync(d_counts, 0, l->nseg * sizeof(uint64_t), l->ctx->stream));
+	}
+	const uint64_t words32 = (l->value_span + 31) / 32; // the odd half of the last 64-bit word, if there is one
+	const uint64_t tail_word = (words32 & 1) ? words32 : ~0ull;
+	const bool edge_cells = edges_only && gl.d_edge_cells != nullptr; // shared words finished inside the scan kernel
+	if (edges_only && !edge_cells && l->sel_edges_groups < l->ngroups) {
 		if (l->d_sel_edges) ADAC_HIP(hipFree(l->d_sel_edges));
 		l->d_sel_edges = nullptr;
 		l->sel_edges_groups = 0;
@@ -1049,11 +1122,9 @@ static adac_status scan_range(adac_layout *l, const uint64_t *d_words, const uin
 	}
 	ADAC_HIP(adac::launch_scan_count_range(l->ctx->stream, l->type_size, gl, d_words, d_validity, blo, bhi - blo, sbit,
 	                                       d_counts, want_bitmap ? d_bitmap : nullptr,
-	                                       edges_only ? l->d_sel_edges : nullptr));
-	if (edges_only) {
-		const uint64_t words32 = (l->value_span + 31) / 32; // the odd half of the last 64-bit word, if there is one
-		ADAC_HIP(adac::launch_sel_merge_edges(l->ctx->stream, l->d_sel_edges, l->ngroups, d_bitmap,
-		                                      (words32 & 1) ? words32 : ~0ull));
+	                                       edges_only && !edge_cells ? l->d_sel_edges : nullptr, edge_cells, tail_word));
+	if (edges_only && !edge_cells) {
+		ADAC_HIP(adac::launch_sel_merge_edges(l->ctx->stream, l->d_sel_edges, l->ngroups, d_bitmap, tail_word));
 	}
 	return ADAC_OK;
 }
@@ -1083,8 +1154,8 @@ extern "C" adac_status adac_unpack_selected(adac_layout *l, const uint64_t *d_wo
 	const uint64_t nblocks = (l->ntiles + 1023) / 1024;
 	uint64_t *d_total = l->d_block_tot + nblocks; // the spare slot after the block totals
 	ADAC_HIP(adac::launch_gather_selected(l->ctx->stream, l->type_size, l->d_descs, l->d_tiles, l->ntiles, d_words,
-	                                      d_bitmap, l->d_tile_cnt, l->d_tile_off, l->d_block_tot, d_out, d_out_ids,
-	                                      d_total));
+	                                      d_bitmap, (l->value_span + 63) / 64, l->d_tile_cnt, l->d_tile_off, l->d_block_tot,
+	                                      d_out, d_out_ids, d_total));
 	if (total_out) return adac_memcpy_d2h(l->ctx, total_out, d_total, sizeof(uint64_t));
 	return ADAC_OK;
 }

@@ -35,24 +35,22 @@ constexpr int kEncPrefetch = 6;                        // rounds of the next seg
 constexpr unsigned long long kScanFlagAggregate = 1ull << 62, kScanFlagPrefix = 2ull << 62, kScanValueMask = (1ull << 62) - 1;
 
 // exclusive prefix of the footprints of segments [0, seg): wave 0 of the workgroup, all 64 lanes.
-// *probe (diagnostic, encode_stamps): round trips that found everything they needed << 16 | round trips that met a
-// predecessor which had not published yet
+// (*probe: a diagnostic of round 3 counted here the round trips that found everything they needed and the ones that
+// met a predecessor which had not published yet — 1.0 - 1.4 against 41 - 43 per segment at the image-flow widths,
+// profiles/r03_encode_lookback.json; the counters cost the 4-byte instantiation its last free registers and are gone)
 __device__ __forceinline__ uint64_t lookback_exclusive(unsigned long long *state, uint32_t seg, uint32_t *probe) {
 	const uint32_t lane = threadIdx.x & 63u;
 	uint64_t sum = 0;
 	int64_t hi = (int64_t)seg - 1; // nearest predecessor not yet accounted for
-	uint32_t trips = 0, waits = 0;
 	while (hi >= 0) {
 		const int64_t idx = hi - (int64_t)lane;
 		unsigned long long v = kScanFlagPrefix; // lanes before segment 0 read as "prefix 0"
 		if (idx >= 0) v = __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		const uint64_t unset = __builtin_amdgcn_ballot_w64((v >> 62) == 0ull);
 		if (unset) {
-			waits++;
 			__builtin_amdgcn_s_sleep(2); // a predecessor has not published its footprint yet
 			continue;
 		}
-		trips++;
 		const uint64_t prefixed = __builtin_amdgcn_ballot_w64((v >> 62) == 2ull);
 		// lanes are ordered nearest predecessor first: take everything up to and including the first prefix
 		const uint32_t stop = prefixed ? (uint32_t)__ffsll((unsigned long long)prefixed) - 1u : 63u;
@@ -62,7 +60,7 @@ __device__ __forceinline__ uint64_t lookback_exclusive(unsigned long long *state
 		if (prefixed) break;
 		hi -= 64;
 	}
-	*probe = (trips << 16) | (waits < 0xffffu ? waits : 0xffffu);
+	(void)probe;
 	return sum;
 }
 
@@ -195,6 +193,27 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 	// of loads is issued (a wave's vector memory operations return in order: behind the loads it would arrive last)
 	uint32_t next_ticket = 0;
 	if (tid == 0) next_ticket = atomicAdd(ticket, 1u);
+	// what phases 2 - 3 produce for a segment (all wave-uniform)
+	struct Analysis {
+		uint64_t mn, mx, stored_min, footprint;
+		uint32_t w;
+		uint8_t flags;
+	};
+	// PUBLISH-AHEAD (ordered placement, parked flow): a segment whose strings are parked in LDS does not ask for its
+	// arena offset — the one point where a workgroup can be held up — before the NEXT segment has been loaded (by every
+	// wave), analysed and its footprint published.  With ordered placement a round of segments advances at the pace of
+	// its slowest workgroup, and a workgroup that waited used to publish its next footprint later still
+	// (profiles/r03_encode_lookback.json); now nobody's footprint waits for anybody's offset.  `pend` = the parked
+	// segment whose offset and stores are still due; it is drained right after the next segment's analysis.
+	struct Pending {
+		bool active;
+		uint32_t seg, n, align, nchunks, nd, skip, nd_total;
+		Analysis a;
+	};
+	Pending pend {};
+	// (8-byte types only: the 4-byte instantiation has no register to spare for the deferred segment's record — 100
+	// spills with it — and takes this kernel only under first-come placement, where nothing waits)
+	constexpr bool kPublishAhead = sizeof(U) == 8;
 
 	for (;;) {
 	// (the thread index is made opaque once per segment: everything derived from it — sixteen rounds of chunk numbers,
@@ -330,12 +349,51 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 		__hip_atomic_store(&scan_state[seg], (seg == 0 ? kScanFlagPrefix : kScanFlagAggregate) | footprint,
 		                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
+	const Analysis ana {mn, mx, stored_min, footprint, w, flags}; // (what the deferred form keeps of this segment)
 	// The arena offset is only needed by the first STORE, and it is obtained as late as that.  The look-back waits for
 	// the slowest of the predecessors in flight (256 workgroups with two segments each: an extreme-value wait of
 	// 5 - 11 us per segment when it followed the publication at once, profiles/r02_encode_experiments_2.json); every
 	// piece of work that fits between publishing the footprint and asking for the prefix shortens it.
 	unsigned long long *__restrict__ dst = nullptr;
-	const int first_come = placement; // 1: arena order = order of completion (no wait at all; offsets differ run to run)
+	const int first_come = placement & 1; // 1: arena order = order of completion (no wait at all; offsets differ run to run)
+	// arena offset of segment `pseg` (analysis `a`), its descriptor and min / max written; returns where its words go
+	auto place_segment = [&](const Analysis &a, uint32_t pseg, bool drain) __attribute__((always_inline)) -> unsigned long long * {
+		const uint32_t seg = pseg; // (the stamp macro names it)
+		if (tid < 64) {
+			uint64_t excl;
+			if (first_come) {
+				unsigned long long got = 0;
+				if (tid == 0) got = atomicAdd(scan_state + nseg + 1, (unsigned long long)a.footprint);
+				excl = uniform64(got);
+			} else {
+				uint32_t probe = 0;
+				excl = seg == 0 ? 0ull : lookback_exclusive(scan_state, seg, &probe);
+				if (stamps && tid == 0u && seg < kEncStampMax) g_enc_stamps[seg * kEncStampSlots + 6] = probe;
+			}
+			if (tid == 0) {
+				if (seg != 0 && !first_come) {
+					__hip_atomic_store(&scan_state[seg], kScanFlagPrefix | (excl + a.footprint), __ATOMIC_RELAXED,
+					                   __HIP_MEMORY_SCOPE_AGENT);
+				}
+				s_word_off = excl;
+				minmax[2 * (uint64_t)seg] = a.mn;
+				minmax[2 * (uint64_t)seg + 1] = a.mx;
+				descs[seg].word_off = excl;
+				descs[seg].min = a.stored_min;
+				descs[seg].width = (uint8_t)a.w;
+				descs[seg].flags = a.flags;
+				descs[seg].reserved = 0;
+			}
+			ADAC_STAMP(5); // (diagnostic: the look-back itself, before the barrier that also waits for the prefetch)
+		}
+		if (drain) {
+			__syncthreads(); // also drains every wave's vmcnt: the LDS-DMA prefetch has landed when the pack is over
+		} else {
+			lds_barrier(); // (the parked flow has the next segment's loads in flight: they must not be waited for)
+		}
+		ADAC_STAMP(3);
+		return reinterpret_cast<unsigned long long *>(words) + uniform64(s_word_off);
+	};
 	auto place = [&](bool drain) {
 		if (tid < 64) {
 			uint64_t excl;
@@ -372,6 +430,46 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 		ADAC_STAMP(3);
 		dst = reinterpret_cast<unsigned long long *>(words) + uniform64(s_word_off);
 	};
+	// the parked strings of a segment (park slots of thread-own rounds) -> the arena
+	auto store_parked = [&](uint32_t *__restrict__ out32, uint32_t pn, uint32_t palign, uint32_t pnchunks, uint32_t nd,
+	                        uint32_t skip, uint32_t nd_total) __attribute__((always_inline)) {
+#pragma unroll
+		for (int r = 0; r < kEncRounds; r++) {
+			const uint32_t round_row = (uint32_t)r * ROUND_ROWS;
+			if (round_row >= pn + palign) continue; // uniform
+			const uint32_t c = (uint32_t)r * kEncThreads + tid;
+			const bool interior = round_row >= palign && round_row + ROUND_ROWS - palign <= pn; // uniform
+			const uint32_t *slot = park + ((uint32_t)r * kEncThreads + tid) * 2u;
+			uint32_t s[2];
+			if (nd == 2u) {
+				const uint2 t2 = *reinterpret_cast<const uint2 *>(slot);
+				s[0] = t2.x, s[1] = t2.y;
+			} else {
+				s[0] = slot[0], s[1] = 0u;
+			}
+			const uint32_t g0 = c * nd - skip;
+			if (interior) {
+				if (nd == 1u) {
+					__builtin_nontemporal_store(s[0], out32 + g0);
+				} else {
+					store_dwords<2>(out32 + g0, s);
+				}
+			} else if (c < pnchunks) {
+#pragma unroll
+				for (uint32_t j = 0; j < 2u; j++) {
+					if (j < nd && g0 + j < nd_total) out32[g0 + j] = s[j];
+				}
+				if (c == pnchunks - 1u && g0 + nd < nd_total) out32[nd_total - 1u] = 0u;
+			}
+		}
+	};
+	// the parked segment before this one: its successor (this segment) is analysed and published — now its offset
+	if constexpr (kPublishAhead) if (pend.active) { // uniform
+		unsigned long long *pdst = place_segment(pend.a, pend.seg, false);
+		store_parked(reinterpret_cast<uint32_t *>(pdst), pend.n, pend.align, pend.nchunks, pend.nd, pend.skip, pend.nd_total);
+		pend.active = false;
+		lds_barrier(); // the parking area is free again before this segment's pack may use the pool
+	}
 	do { // phase 4 (left with `break` where the one-segment form returned)
 	// whole-dword strings (4a below)?  With at most two dwords per chunk the strings are PARKED in LDS, the next
 	// segment's loads are issued into the freed registers, and only then is the arena offset asked for: the look-back
@@ -446,37 +544,52 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 				}
 			};
 			const bool more = nxt.seg < nseg; // uniform
+			// Deferring pays when the NEXT segment parks too (then nothing but its analysis stands between this point and
+			// the drain); next to segments of another flow it costs: on a column that alternates between the flows (u64
+			// w = 16: a segment at an odd element offset cannot park) it ran 2.5x slower.  The next width is not known
+			// yet; at w = 32 every segment parks whatever its placement, so that is where it is done.
+			if (kPublishAhead && more && !first_come && (placement & 2) && w == 32u) { // uniform: publish-ahead (see `pend`)
+				if (tid == 0) next_ticket = atomicAdd(ticket, 1u); // the segment after the next: before this wave's loads
+				load_next();
+				pend = Pending {true, seg, n, align, nchunks, nd, skip, nd_total, ana};
+				next_loaded = true;
+				break;
+			}
 			if (more && tid >= 64u) load_next();
 			place(false);
 			// ... and the strings leave for the arena
-			uint32_t *__restrict__ out32 = reinterpret_cast<uint32_t *>(dst);
+			if constexpr (kPublishAhead) {
+				store_parked(reinterpret_cast<uint32_t *>(dst), n, align, nchunks, nd, skip, nd_total);
+			} else {
+				uint32_t *__restrict__ out32 = reinterpret_cast<uint32_t *>(dst);
 #pragma unroll
-			for (int r = 0; r < kEncRounds; r++) {
-				const uint32_t round_row = (uint32_t)r * ROUND_ROWS;
-				if (round_row >= n + align) continue; // uniform
-				const uint32_t c = (uint32_t)r * kEncThreads + tid;
-				const bool interior = round_row >= align && round_row + ROUND_ROWS - align <= n; // uniform
-				const uint32_t *slot = park + ((uint32_t)r * kEncThreads + tid) * 2u;
-				uint32_t s[2];
-				if (nd == 2u) {
-					const uint2 t2 = *reinterpret_cast<const uint2 *>(slot);
-					s[0] = t2.x, s[1] = t2.y;
-				} else {
-					s[0] = slot[0], s[1] = 0u;
-				}
-				const uint32_t g0 = c * nd - skip;
-				if (interior) {
-					if (nd == 1u) {
-						__builtin_nontemporal_store(s[0], out32 + g0);
+				for (int r = 0; r < kEncRounds; r++) {
+					const uint32_t round_row = (uint32_t)r * ROUND_ROWS;
+					if (round_row >= n + align) continue; // uniform
+					const uint32_t c = (uint32_t)r * kEncThreads + tid;
+					const bool interior = round_row >= align && round_row + ROUND_ROWS - align <= n; // uniform
+					const uint32_t *slot = park + ((uint32_t)r * kEncThreads + tid) * 2u;
+					uint32_t s[2];
+					if (nd == 2u) {
+						const uint2 t2 = *reinterpret_cast<const uint2 *>(slot);
+						s[0] = t2.x, s[1] = t2.y;
 					} else {
-						store_dwords<2>(out32 + g0, s);
+						s[0] = slot[0], s[1] = 0u;
 					}
-				} else if (c < nchunks) {
+					const uint32_t g0 = c * nd - skip;
+					if (interior) {
+						if (nd == 1u) {
+							__builtin_nontemporal_store(s[0], out32 + g0);
+						} else {
+							store_dwords<2>(out32 + g0, s);
+						}
+					} else if (c < nchunks) {
 #pragma unroll
-					for (uint32_t j = 0; j < 2u; j++) {
-						if (j < nd && g0 + j < nd_total) out32[g0 + j] = s[j];
+						for (uint32_t j = 0; j < 2u; j++) {
+							if (j < nd && g0 + j < nd_total) out32[g0 + j] = s[j];
+						}
+						if (c == nchunks - 1u && g0 + nd < nd_total) out32[nd_total - 1u] = 0u;
 					}
-					if (c == nchunks - 1u && g0 + nd < nd_total) out32[nd_total - 1u] = 0u;
 				}
 			}
 			if (more && tid < 64u) {

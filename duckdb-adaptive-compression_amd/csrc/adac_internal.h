@@ -23,18 +23,31 @@ struct TileRef {
 // layout and grouping), and its expansion with the segment's current descriptor (rebuilt whenever descriptors
 // change): a scan workgroup then needs ONE 64-byte load before its first data load instead of the dependent
 // chain tile entry -> descriptor.
+// The ARRIVAL fields (round 3) let a scan finish its results inside the one kernel — no clearing pass before it and no
+// merge kernel after it: `seg_groups` groups add into the segment's result cell and the last one to arrive stores the
+// total; a bitmap word that several groups cover in part (dense value spaces only) is ORed into an edge cell by
+// `n_first` / `n_last` groups and stored by the last of them.  Cells are zero between calls (the last arriver resets).
 struct ScanGroupRef {
 	uint32_t seg;
 	uint32_t first;
 	uint32_t rows; // a segment's tiles are dealt evenly to its groups, so group sizes differ between segments
+	uint32_t seg_groups; // scan groups of this segment
+	uint32_t cell_first; // edge cell of the group's first bitmap word when that word is covered in part
+	uint32_t cell_last;  // ... of its last word (groups of more than one word)
+	uint16_t n_first;    // groups that cover the first word in part (0: the word is whole, or the value space has gaps)
+	uint16_t n_last;
 	uint32_t pad;
 };
+static_assert(sizeof(ScanGroupRef) == 32, "device record");
 struct alignas(64) ScanGroup {
 	adac_segment_desc d;
 	uint32_t seg;
 	uint32_t first;
 	uint32_t n; // rows
-	uint32_t pad[5];
+	uint32_t seg_groups;
+	uint32_t cell_first, cell_last;
+	uint16_t n_first, n_last;
+	uint32_t pad;
 };
 static_assert(sizeof(ScanGroup) == 64, "one cache-line record per scan group");
 
@@ -74,8 +87,11 @@ struct Tuning {
 	int group_sum_wide = 0;     // A/B: adac_scan_group_sum always in 64-bit arithmetic
 	int group_sum_rw = 1;       // A/B: 0 = adac_scan_group_sum without the register-walk kernel (k_group_sum only)
 	int encode_placement = 0;   // single-pass encode: 0 = arena order is segment order (look-back), 1 = order of completion
+	int encode_publish_ahead = 1; // single-pass encode, ordered placement: the parked flow publishes the NEXT footprint before it waits (A/B: 0)
 	int encode_stamps = 0;      // diagnostic: phase time stamps of the single-pass encode (adac_debug_encode_stamps)
 	int grouped_repack = 1;     // A/B: 0 = one tile per workgroup with the 16 KiB row image (the first version)
+	int scan_cells = 1;         // fused scans: 1 = results (and shared bitmap words) finished inside the scan kernel through arrival cells, 0 = clearing pass + atomics (+ merge kernel)
+	int gather_compact = 3;     // adac_unpack_selected: 0 = a store per selected row (k_gather), 1 = wave-level compaction + dense stores (k_gather_c), 3 = the same with non-temporal stores
 	int sel_debug = 0;          // diagnostic: selection scan without its flush (1) / without any bitmap emit (2)
 	int scan_probe = 0;         // diagnostic: fused-scan loop + loads only (no field walk)
 	int templated_scan = 1;     // width-templated register path of the fused scans for 4 <= w <= 32
@@ -141,13 +157,19 @@ struct ScanGroupList {
 	uint64_t ngroups;
 	const uint32_t *d_narrow_idx;
 	uint32_t n_narrow;
+	// arrival cells (see ScanGroupRef), zero between calls; nullptr: the clearing pass + atomics form
+	unsigned long long *d_res_cells; // per segment: four words (arrive_sum / arrive_count)
+	uint32_t *d_edge_cells;          // two per group: one 64-bit word each (arrive_or)
 };
+inline uint64_t scan_res_cell_bytes(uint64_t nseg) { return (nseg ? nseg : 1) * 4 * sizeof(unsigned long long); }
+inline uint64_t scan_edge_cell_bytes(uint64_t ngroups) { return (ngroups ? ngroups : 1) * 4 * sizeof(uint32_t); }
 hipError_t launch_expand_groups(hipStream_t s, const adac_segment_desc *d_descs, const ScanGroupRef *d_refs,
                                 uint64_t ngroups, ScanGroup *d_groups, uint32_t *d_narrow_idx, uint32_t *d_narrow_count);
 hipError_t launch_gather_selected(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs,
                                   const TileRef *d_tiles, uint64_t ntiles, const uint64_t *d_words,
-                                  const uint64_t *d_bitmap, uint32_t *d_tile_cnt, uint64_t *d_tile_off,
-                                  uint64_t *d_block_tot, void *d_out, uint64_t *d_out_ids, uint64_t *d_total);
+                                  const uint64_t *d_bitmap, uint64_t bitmap_words, uint32_t *d_tile_cnt,
+                                  uint64_t *d_tile_off, uint64_t *d_block_tot, void *d_out, uint64_t *d_out_ids,
+                                  uint64_t *d_total);
 hipError_t launch_scan_sum(hipStream_t s, uint32_t type_size, const ScanGroupList &gl, const uint64_t *d_words,
                            const uint64_t *d_validity, uint64_t sbit, uint64_t *d_sums);
 uint64_t sel_edge_bytes(uint64_t ngroups);
@@ -155,7 +177,8 @@ hipError_t launch_sel_merge_edges(hipStream_t s, const void *d_edges, uint64_t n
                                   uint64_t tail_word);
 hipError_t launch_scan_count_range(hipStream_t s, uint32_t type_size, const ScanGroupList &gl, const uint64_t *d_words,
                                    const uint64_t *d_validity, uint64_t blo, uint64_t bspan, uint64_t sbit,
-                                   uint64_t *d_counts, uint64_t *d_bitmap, void *d_edges);
+                                   uint64_t *d_counts, uint64_t *d_bitmap, void *d_edges, bool edge_cells,
+                                   uint64_t tail_word);
 
 // Persistent block images (adac_block_image.inl): one segment's packed words <-> its image in a block buffer.
 struct BlockJob {

@@ -157,14 +157,16 @@ __device__ __forceinline__ void read_field(const uint32_t *lds32, uint32_t bit, 
 // Walk the rows of a staged tile in chunks of K = 16/sizeof(U) consecutive rows, chunk boundaries aligned to
 // 16 bytes of the OUTPUT element index (elem0 + row), so a sink can use one dwordx4 store per full chunk.
 // sink(base, vals, full): `base` = tile-local row of vals[0] (may be < 0 or run past n on partial chunks).
-template <typename U, bool WIDE, typename Sink>
+// WAVE: the trip count is the same for the 64 lanes of a wave (a sink with cross-lane operations: k_gather); lanes whose
+// chunk lies past the tile call the sink with base >= n and full = false.
+template <typename U, bool WIDE, bool WAVE = false, typename Sink>
 __device__ __forceinline__ void decode_rows(const uint32_t *lds32, uint32_t bit0, uint32_t w, uint64_t add, uint32_t n,
                                             uint32_t align, Sink &&sink) {
 	constexpr int K = 16 / (int)sizeof(U);
 	const uint32_t mlo = WIDE ? 0xffffffffu : mask32(w);
 	const uint32_t mhi = WIDE ? mask32(w - 32u) : 0u;
 	const uint32_t add_lo = (uint32_t)add;
-	for (uint32_t c = threadIdx.x; c * K < n + align; c += kWorkgroup) {
+	for (uint32_t c = threadIdx.x; (WAVE ? (c & ~63u) : c) * K < n + align; c += kWorkgroup) {
 		const int32_t base = (int32_t)(c * K) - (int32_t)align;
 		U vals[K];
 #pragma unroll
@@ -253,7 +255,7 @@ __device__ __forceinline__ void decode_full_tile_u8(const uint32_t *lds32, uint3
 }
 
 // One staged tile -> sink, choosing the two/three-dword window and the full-tile fast path (both wave-uniform).
-template <typename U, typename Sink>
+template <typename U, bool WAVE = false, typename Sink>
 __device__ __forceinline__ void decode_tile(const uint32_t *lds32, uint32_t bit0, uint32_t w, uint64_t add, uint32_t n,
                                             uint32_t align, Sink &&sink) {
 	constexpr uint32_t TILE = kTileBytes / sizeof(U);
@@ -276,13 +278,13 @@ __device__ __forceinline__ void decode_tile(const uint32_t *lds32, uint32_t bit0
 		if (fast) {
 			decode_full_tile<U, true>(lds32, bit0, w, add, sink);
 		} else {
-			decode_rows<U, true>(lds32, bit0, w, add, n, align, sink);
+			decode_rows<U, true, WAVE>(lds32, bit0, w, add, n, align, sink);
 		}
 	} else {
 		if (fast) {
 			decode_full_tile<U, false>(lds32, bit0, w, add, sink);
 		} else {
-			decode_rows<U, false>(lds32, bit0, w, add, n, align, sink);
+			decode_rows<U, false, WAVE>(lds32, bit0, w, add, n, align, sink);
 		}
 	}
 }
@@ -442,15 +444,20 @@ __device__ __forceinline__ bool scan_width_is_narrow(uint32_t w) { return w == 2
 // cost 3 - 5 % of a fused scan once the narrow-width test made width the first field needed,
 // profiles/r03_scan_split_ab.json).
 __device__ __forceinline__ ScanGroup load_scan_group(const ScanGroup *__restrict__ groups, uint32_t gi) {
-	static_assert(sizeof(ScanGroup) == 64 && offsetof(ScanGroup, seg) == 32, "record layout");
+	static_assert(sizeof(ScanGroup) == 64 && offsetof(ScanGroup, seg) == 32 && offsetof(ScanGroup, n_first) == 56,
+	              "record layout");
 	ScanGroup g;
 	g.d = load_desc(&groups[gi].d);
 	const uint32_t *__restrict__ p = reinterpret_cast<const uint32_t *>(groups + gi);
 	g.seg = p[8];
 	g.first = p[9];
 	g.n = p[10];
-#pragma unroll
-	for (int i = 0; i < 5; i++) g.pad[i] = 0;
+	g.seg_groups = p[11];
+	g.cell_first = p[12];
+	g.cell_last = p[13];
+	g.n_first = (uint16_t)(p[14] & 0xffffu);
+	g.n_last = (uint16_t)(p[14] >> 16);
+	g.pad = 0;
 	return g;
 }
 
@@ -483,7 +490,105 @@ struct SelOut {
 	int debug;          // diagnostic (adac_set_tuning "sel_debug"): 1 = no write-out, 2 = no emit at all (results wrong)
 	SelEdge *edges;     // dense value spaces: the group's two records for the words it shares (nullptr: global atomicOr)
 	bool nt;            // A/B: non-temporal bitmap stores
+	// dense value spaces, arrival form (round 3): the edge cells and this group's ScanGroupRef arrival fields
+	unsigned long long *cells;
+	uint32_t cell_first, cell_last, n_first, n_last;
 };
+
+// ---------------------------------------------------------------------------------------------
+// Arrival cells: results finished INSIDE the scan kernel.  Every party adds (ORs) its part into a cell and then counts
+// itself in; the one that completes the expected number takes the cell's content, stores the result with a plain
+// store and leaves the cell zero for the next call.  No clearing pass before the scan and no merge kernel after it
+// (at C2 they cost 3.4 us of a 73 us SUM and 8.7 us of an 85 us selection scan: launch gaps, not work).  The two
+// atomics of a party are ordered by waiting for the first one's acknowledgement (vmcnt): both are performed at the
+// agent's point of coherence, so whoever sees the completing count also sees every part.
+// ---------------------------------------------------------------------------------------------
+// A 64-bit sum (mod 2^64) does not fit one word together with the arrivals, so its two 32-bit halves travel in TWO words,
+// each with its own arrival count in bits 40 and up (the halves of up to 256 parts add up below 2^40), both atomics in
+// flight together: one round trip.  Whoever completes both words knows the total.  When two different parties complete
+// one word each (their atomics interleaved), they meet at a third word: the first leaves its half there, the second
+// takes it, stores the total and clears the word.  Segments of more than 256 groups: add, wait, count (two trips).
+constexpr uint32_t kArriveShift = 40;
+// (`swapped`: test hook, sel_debug 7 — this party sends the high half first and waits for it, so that two parties of a
+// segment complete one word each and the meeting at the third word is exercised)
+__device__ __forceinline__ void arrive_sum(unsigned long long *cell, uint64_t part, uint32_t expected,
+                                           uint64_t *__restrict__ dst, bool swapped) {
+	if (expected <= 1u) {
+		*dst = part;
+		return;
+	}
+	if (expected > 256u) {
+		if (part) {
+			__hip_atomic_fetch_add(cell, (unsigned long long)part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		}
+		const unsigned long long before = __hip_atomic_fetch_add(cell + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (before + 1ull == expected) {
+			*dst = __hip_atomic_exchange(cell, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_store(cell + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		return;
+	}
+	constexpr unsigned long long one = 1ull << kArriveShift;
+	const uint64_t lo = part & 0xffffffffull, hi = part >> 32;
+	unsigned long long oa, ob;
+	if (swapped) {
+		ob = __hip_atomic_fetch_add(cell + 1, one | hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__builtin_amdgcn_s_sleep(64);
+		oa = __hip_atomic_fetch_add(cell, one | lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	} else {
+		oa = __hip_atomic_fetch_add(cell, one | lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		ob = __hip_atomic_fetch_add(cell + 1, one | hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+	const bool last_a = (uint32_t)(oa >> kArriveShift) + 1u == expected;
+	const bool last_b = (uint32_t)(ob >> kArriveShift) + 1u == expected;
+	const uint64_t ta = (oa & (one - 1ull)) + lo, tb = (ob & (one - 1ull)) + hi; // <= 2^40 each
+	if (last_a) __hip_atomic_store(cell, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	if (last_b) __hip_atomic_store(cell + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	if (last_a && last_b) {
+		*dst = (tb << 32) + ta;
+	} else if (last_a || last_b) {
+		const unsigned long long other =
+		    __hip_atomic_exchange(cell + 2, (1ull << 63) | (last_a ? ta : tb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (other) { // the completer of the other half was here first
+			const uint64_t o = other & ~(1ull << 63);
+			*dst = last_a ? ((o << 32) + ta) : ((tb << 32) + o);
+			__hip_atomic_store(cell + 2, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+	}
+}
+// Parts that fit 40 bits and add up below 2^40 (a segment's hit count: at most 2^32 rows) travel WITH the arrival in
+// one atomic — arrivals << 40 | sum — so a party needs a single round trip and the completing one knows the total
+// from the value it got back.
+__device__ __forceinline__ void arrive_count(unsigned long long *cell, uint64_t part, uint32_t expected,
+                                             uint64_t *__restrict__ dst) {
+	if (expected <= 1u) {
+		*dst = part;
+		return;
+	}
+	const unsigned long long before =
+	    __hip_atomic_fetch_add(cell, (1ull << kArriveShift) | part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	if ((uint32_t)(before >> kArriveShift) + 1u == expected) {
+		*dst = (before & ((1ull << kArriveShift) - 1ull)) + part;
+		__hip_atomic_store(cell, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+}
+// Bits of one bitmap word: the parties' bits are disjoint (different rows), so OR is ADD and they too travel with the
+// arrival: arrivals << 32 | bits.
+__device__ __forceinline__ void arrive_or(unsigned long long *cell, uint32_t part, uint32_t expected,
+                                          uint32_t *__restrict__ dst) {
+	if (expected <= 1u) {
+		*dst = part;
+		return;
+	}
+	const unsigned long long before =
+	    __hip_atomic_fetch_add(cell, (1ull << 32) | part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	if ((uint32_t)(before >> 32) + 1u == expected) {
+		*dst = (uint32_t)before | part;
+		__hip_atomic_store(cell, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+}
 
 __device__ __forceinline__ void sel_or(const SelOut &o, uint32_t p, uint32_t bits, uint32_t nbits) {
 	if (bits) {
@@ -507,6 +612,9 @@ __device__ __forceinline__ void sel_write_out(const SelOut &o, uint32_t *__restr
 			} else {
 				*g = v;
 			}
+		} else if (o.cells) { // only the first and the last word of the group can be covered in part
+			const bool head = i == 0u;
+			arrive_or(o.cells + (head ? o.cell_first : o.cell_last), v, head ? o.n_first : o.n_last, g);
 		} else if (o.edges) { // only the first and the last word of the group can be shared
 			SelEdge e;
 			e.word = (uint64_t)(g - o.bitmap32);
@@ -811,8 +919,12 @@ __global__ void k_expand_groups(const adac_segment_desc *__restrict__ descs, con
 	out.seg = r.seg;
 	out.first = r.first;
 	out.n = r.rows;
-#pragma unroll
-	for (int i = 0; i < 5; i++) out.pad[i] = 0;
+	out.seg_groups = r.seg_groups;
+	out.cell_first = r.cell_first;
+	out.cell_last = r.cell_last;
+	out.n_first = r.n_first;
+	out.n_last = r.n_last;
+	out.pad = 0;
 	groups[g] = out;
 	// the groups of segments at widths 2 and 3 are also listed for the narrow scan kernel (order of arrival: the list
 	// only says who runs, every result is an exact integer)
@@ -861,7 +973,9 @@ template <typename U, int OP, bool V, bool NARROW>
 __global__ __launch_bounds__(kWorkgroup, NARROW ? 4 : 6) void k_scan_agg(
     const ScanGroup *__restrict__ groups, const uint32_t *__restrict__ narrow_idx, int templated,
     const uint64_t *__restrict__ words, RangePred pred, const uint64_t *__restrict__ validity,
-    uint64_t *__restrict__ result, uint32_t *__restrict__ bitmap32, SelEdge *__restrict__ edges) {
+    uint64_t *__restrict__ result, uint32_t *__restrict__ bitmap32, SelEdge *__restrict__ edges,
+    unsigned long long *__restrict__ res_cells, uint32_t *__restrict__ edge_cells, uint32_t last_group,
+    uint64_t tail_word) {
 	// LDS: the packed image of one stage of the fallback path (the register path uses none) and, for the selection
 	// scan, the bitmap image of the group.  The selection scan halves the stage so that both fit 16.4 KiB: at
 	// 24.6 KiB only six workgroups fit a CU instead of eight, and these kernels are bound by the bytes a CU keeps
@@ -875,8 +989,10 @@ __global__ __launch_bounds__(kWorkgroup, NARROW ? 4 : 6) void k_scan_agg(
 	const ScanGroup g = load_scan_group(groups, gi);
 	const adac_segment_desc &d = g.d;
 	if (!NARROW && kScanHasNarrowKernel<OP, V> && scan_width_is_narrow(d.width)) return; // the narrow kernel's group
-	SelOut sel_out {sel_img, bitmap32, 0u, (templated >> 1) == 6 ? 0 : (templated >> 1),
-	                edges ? edges + 2u * (uint64_t)gi : nullptr, (templated >> 1) == 6};
+	const bool arrive_swapped = (templated >> 1) == 7 && (gi & 1u); // test hook of arrive_sum
+	SelOut sel_out {sel_img, bitmap32, 0u, (templated >> 1) >= 6 ? 0 : (templated >> 1),
+	                edges ? edges + 2u * (uint64_t)gi : nullptr, (templated >> 1) == 6,
+	                reinterpret_cast<unsigned long long *>(edge_cells), g.cell_first, g.cell_last, g.n_first, g.n_last};
 	templated &= 1;
 	const uint32_t sel_p0 = (uint32_t)(d.val_off & 31u) + g.first; // the group's positions [sel_p0, sel_p0 + n)
 	if (OP == 3) {
@@ -946,12 +1062,27 @@ __global__ __launch_bounds__(kWorkgroup, NARROW ? 4 : 6) void k_scan_agg(
 			done += n;
 		}
 	}
-	if (OP == 3) {
-		__syncthreads(); // every wave's bits are in the image
-		if (sel_out.debug == 0) sel_write_out(sel_out, bitmap32 + (d.val_off >> 5), sel_p0, sel_p0 + g.n);
-	}
 	const uint64_t tot = wave_sum(acc);
-	if ((threadIdx.x & 63) == 0 && tot != 0) { // wrapping sums commute: one atomic per wave and group
+	__shared__ uint64_t wave_tot[kWorkgroup / 64];
+	if (res_cells && (threadIdx.x & 63u) == 0u) wave_tot[threadIdx.x >> 6] = tot;
+	if (OP == 3 || res_cells) __syncthreads(); // every wave's bits are in the image / every wave's total is in LDS
+	if (OP == 3) {
+		if (sel_out.debug == 0) sel_write_out(sel_out, bitmap32 + (d.val_off >> 5), sel_p0, sel_p0 + g.n);
+		// the odd 32-bit half of the bitmap's last 64-bit word belongs to no group
+		if (edge_cells && gi == last_group && tail_word != ~0ull && threadIdx.x == 128u) bitmap32[tail_word] = 0u;
+	}
+	if (res_cells) { // the group's total: one party per group at the segment's result cell (a wave that has no edge word)
+		if (threadIdx.x == 64u) {
+			uint64_t all = 0;
+#pragma unroll
+			for (int i = 0; i < kWorkgroup / 64; i++) all += wave_tot[i];
+			if (OP == 1 || OP == 3) {
+				arrive_count(res_cells + 4u * (uint64_t)g.seg, all, g.seg_groups, result + g.seg);
+			} else {
+				arrive_sum(res_cells + 4u * (uint64_t)g.seg, all, g.seg_groups, result + g.seg, arrive_swapped);
+			}
+		}
+	} else if ((threadIdx.x & 63) == 0 && tot != 0) { // wrapping sums commute: one atomic per wave and group
 		atomicAdd(reinterpret_cast<unsigned long long *>(result + g.seg), (unsigned long long)tot);
 	}
 }
@@ -2102,7 +2233,8 @@ hipError_t launch_encode_1p(hipStream_t s, uint32_t type_size, bool sign_extend,
 		unsigned long long *state = static_cast<unsigned long long *>(d_scan_state);
 		hipLaunchKernelGGL(k_encode_1p<U>, dim3(grid), dim3(kEncThreads), 0, s, d_descs, d_descs, (uint32_t)nseg, d_minmax,
 		                   static_cast<const U *>(d_vals), d_validity, sign_extend ? 1 : 0, null_bits, rule, pad_to_byte,
-		                   state, reinterpret_cast<uint32_t *>(state + nseg), d_words, g_tuning.encode_stamps, g_tuning.encode_placement);
+		                   state, reinterpret_cast<uint32_t *>(state + nseg), d_words, g_tuning.encode_stamps,
+		                   (g_tuning.encode_placement & 1) | (g_tuning.encode_publish_ahead ? 2 : 0));
 		return hipGetLastError();
 	});
 }
@@ -2255,21 +2387,23 @@ hipError_t launch_scan_sum(hipStream_t s, uint32_t type_size, const ScanGroupLis
 	return dispatch_size(type_size, [&](auto tag) {
 		using U = decltype(tag);
 		const dim3 grid((unsigned)gl.ngroups);
-		const int tpl = g_tuning.templated_scan;
+		const int tpl = g_tuning.templated_scan | (g_tuning.sel_debug == 7 ? 7 << 1 : 0);
 		uint32_t *no_bitmap = nullptr;
 		SelEdge *no_edges = nullptr;
 		if (g_tuning.scan_probe) { // diagnostic: the scan's loop and loads without the field walk (result meaningless)
 			hipLaunchKernelGGL((k_scan_agg<U, 2, false, false>), grid, dim3(kWorkgroup), 0, s, gl.d_groups, gl.d_narrow_idx,
-			                   1, d_words, RangePred {}, static_cast<const uint64_t *>(nullptr), d_sums, no_bitmap, no_edges);
+			                   1, d_words, RangePred {}, static_cast<const uint64_t *>(nullptr), d_sums, no_bitmap, no_edges,
+			                   gl.d_res_cells, no_bitmap, 0u, ~0ull);
 		} else if (d_validity) {
 			hipLaunchKernelGGL((k_scan_agg<U, 0, true, false>), grid, dim3(kWorkgroup), 0, s, gl.d_groups, gl.d_narrow_idx,
-			                   tpl, d_words, widen, d_validity, d_sums, no_bitmap, no_edges);
+			                   tpl, d_words, widen, d_validity, d_sums, no_bitmap, no_edges, gl.d_res_cells, no_bitmap, 0u, ~0ull);
 		} else {
 			hipLaunchKernelGGL((k_scan_agg<U, 0, false, false>), grid, dim3(kWorkgroup), 0, s, gl.d_groups, gl.d_narrow_idx,
-			                   tpl, d_words, widen, d_validity, d_sums, no_bitmap, no_edges);
+			                   tpl, d_words, widen, d_validity, d_sums, no_bitmap, no_edges, gl.d_res_cells, no_bitmap, 0u, ~0ull);
 			if (gl.n_narrow) {
 				hipLaunchKernelGGL((k_scan_agg<U, 0, false, true>), dim3(gl.n_narrow), dim3(kWorkgroup), 0, s, gl.d_groups,
-				                   gl.d_narrow_idx, tpl, d_words, widen, d_validity, d_sums, no_bitmap, no_edges);
+				                   gl.d_narrow_idx, tpl, d_words, widen, d_validity, d_sums, no_bitmap, no_edges,
+				                   gl.d_res_cells, no_bitmap, 0u, ~0ull);
 			}
 		}
 		return hipGetLastError();
@@ -2288,8 +2422,11 @@ hipError_t launch_sel_merge_edges(hipStream_t s, const void *d_edges, uint64_t n
 
 hipError_t launch_scan_count_range(hipStream_t s, uint32_t type_size, const ScanGroupList &gl, const uint64_t *d_words,
                                    const uint64_t *d_validity, uint64_t blo, uint64_t bspan, uint64_t sbit,
-                                   uint64_t *d_counts, uint64_t *d_bitmap, void *d_edges) {
+                                   uint64_t *d_counts, uint64_t *d_bitmap, void *d_edges, bool edge_cells,
+                                   uint64_t tail_word) {
 	if (gl.ngroups == 0) return hipSuccess;
+	uint32_t *const ecells = edge_cells ? gl.d_edge_cells : nullptr;
+	const uint32_t last_group = (uint32_t)(gl.ngroups - 1);
 	return dispatch_size(type_size, [&](auto tag) {
 		using U = decltype(tag);
 		const dim3 grid((unsigned)gl.ngroups);
@@ -2300,11 +2437,12 @@ hipError_t launch_scan_count_range(hipStream_t s, uint32_t type_size, const Scan
 #define ADAC_SCAN(OPN, VAL)                                                                                            \
 	do {                                                                                                               \
 		hipLaunchKernelGGL((k_scan_agg<U, OPN, VAL, false>), grid, dim3(kWorkgroup), 0, s, gl.d_groups, gl.d_narrow_idx, \
-		                   tpl, d_words, pred, d_validity, d_counts, bm, static_cast<SelEdge *>(d_edges));               \
+		                   tpl, d_words, pred, d_validity, d_counts, bm, static_cast<SelEdge *>(d_edges),                \
+		                   gl.d_res_cells, ecells, last_group, tail_word);                                               \
 		if (gl.n_narrow) {                                                                                             \
 			hipLaunchKernelGGL((k_scan_agg<U, OPN, VAL, true>), dim3(gl.n_narrow), dim3(kWorkgroup), 0, s, gl.d_groups,  \
 			                   gl.d_narrow_idx, tpl, d_words, pred, d_validity, d_counts, bm,                            \
-			                   static_cast<SelEdge *>(d_edges));                                                         \
+			                   static_cast<SelEdge *>(d_edges), gl.d_res_cells, ecells, last_group, tail_word);          \
 		}                                                                                                              \
 	} while (0)
 		if (d_bitmap) {
@@ -2410,8 +2548,9 @@ hipError_t launch_bp_fetch(hipStream_t s, uint32_t type_size, const uint64_t *d_
 
 hipError_t launch_gather_selected(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs,
                                   const TileRef *d_tiles, uint64_t ntiles, const uint64_t *d_words,
-                                  const uint64_t *d_bitmap, uint32_t *d_tile_cnt, uint64_t *d_tile_off,
-                                  uint64_t *d_block_tot, void *d_out, uint64_t *d_out_ids, uint64_t *d_total) {
+                                  const uint64_t *d_bitmap, uint64_t bitmap_words, uint32_t *d_tile_cnt,
+                                  uint64_t *d_tile_off, uint64_t *d_block_tot, void *d_out, uint64_t *d_out_ids,
+                                  uint64_t *d_total) {
 	if (ntiles == 0) return hipMemsetAsync(d_total, 0, sizeof(uint64_t), s);
 	return dispatch_size(type_size, [&](auto tag) {
 		using U = decltype(tag);
@@ -2423,8 +2562,14 @@ hipError_t launch_gather_selected(hipStream_t s, uint32_t type_size, const adac_
 		                   d_block_tot);
 		hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(kScanBlock), 0, s, d_block_tot, nblocks, d_total);
 		hipLaunchKernelGGL(k_scan_fixup, dim3((unsigned)nblocks), dim3(kScanBlock), 0, s, d_tile_off, ntiles, d_block_tot);
-		hipLaunchKernelGGL(k_gather<U>, dim3((unsigned)ntiles), dim3(kWorkgroup), 0, s, d_descs, d_tiles, d_words,
-		                   d_bitmap, d_tile_off, static_cast<U *>(d_out), d_out_ids);
+		if (g_tuning.gather_compact && bitmap_words < (1ull << 31)) { // (32-bit dword indices into the bitmap)
+			hipLaunchKernelGGL(k_gather_c<U>, dim3((unsigned)ntiles), dim3(kWorkgroup), 0, s, d_descs, d_tiles, d_words,
+			                   d_bitmap, (uint32_t)(2 * bitmap_words - 1), d_tile_off, static_cast<U *>(d_out), d_out_ids,
+			                   g_tuning.gather_compact & 2);
+		} else {
+			hipLaunchKernelGGL(k_gather<U>, dim3((unsigned)ntiles), dim3(kWorkgroup), 0, s, d_descs, d_tiles, d_words,
+			                   d_bitmap, d_tile_off, static_cast<U *>(d_out), d_out_ids);
+		}
 		return hipGetLastError();
 	});
 }

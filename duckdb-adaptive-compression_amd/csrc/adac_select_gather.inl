@@ -144,3 +144,223 @@ __global__ __launch_bounds__(kWorkgroup) void k_gather(const adac_segment_desc *
 	};
 	decode_tile<U>(reinterpret_cast<const uint32_t *>(lds), bit0, t.d.width, effective_add(t.d), t.n, 0u, sink);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_gather_c — the same gather with WAVE-LEVEL COMPACTION (round 3).  k_gather stores every selected row with a store
+// of its own (two per row with the ids): at 50 % selectivity four half-empty 8-byte store instructions per chunk where
+// k_unpack issues one full dwordx4, and the L2 merges the partial lines: 335 us for the bytes k_unpack moves in 199.
+// Here a wave compacts the rows it decodes in one round — 64 consecutive chunks, i.e. ONE contiguous run of rows whose
+// selected rows are one contiguous run of output slots — in an LDS buffer of its own and writes them out densely, a
+// 16-byte unit per lane, the buffer laid out at the output's own 16-byte phase (first / last unit: element stores).
+// No workgroup barrier after the staging one and no chunk-offset table: every wave derives the sixteen run offsets of
+// the tile itself (a lane per bitmap word or group of words, one DPP scan; the four waves repeat 256 - 2048 bytes of
+// bitmap reads), the position inside a run is a second DPP scan per round.  LDS operations of one wave execute in
+// order, so the write -> read -> next round's write sequence on the wave's buffer needs no barrier.
+// ---------------------------------------------------------------------------------------------------------------------
+// Selection bits starting at element e (bit j = element e + j) from the bitmap read as 32-bit words: every load is
+// UNCONDITIONAL, its index clamped to the bitmap's last dword (never over-read).  The form with the second word under a
+// condition (validity_window) compiled to a branch per call and the five windows of a lane — four rounds and the
+// tile-wide prefix — went out one round trip after the other.
+// (dword indices in 32 bits — the launcher takes this kernel for bitmaps of less than 2^32 dwords only — so a clamp is
+// one v_min_u32; with 64-bit indices each was a compare and two selects and the 1-byte types, twelve loads a lane in
+// the prefix pass, lost 9 %)
+__device__ __forceinline__ uint32_t bitmap_bits32(const uint32_t *__restrict__ bm32, uint32_t last_dword, uint64_t e) {
+	const uint32_t dw = (uint32_t)(e >> 5);
+	const uint32_t lo = bm32[dw < last_dword ? dw : last_dword];
+	const uint32_t hi = bm32[dw + 1u < last_dword ? dw + 1u : last_dword];
+	return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)e & 31u);
+}
+// popcount of the first `have` (0 .. 64 * WORDS) of the 64 * WORDS bits starting at element e: 2 * WORDS + 1 loads
+template <int WORDS>
+__device__ __forceinline__ uint32_t bitmap_popc(const uint32_t *__restrict__ bm32, uint32_t last_dword, uint64_t e,
+                                                uint32_t have) {
+	const uint32_t dw = (uint32_t)(e >> 5), sh = (uint32_t)e & 31u;
+	uint32_t d[2 * WORDS + 1];
+#pragma unroll
+	for (int i = 0; i <= 2 * WORDS; i++) d[i] = bm32[dw + (uint32_t)i < last_dword ? dw + (uint32_t)i : last_dword];
+	uint32_t c = 0;
+#pragma unroll
+	for (int i = 0; i < 2 * WORDS; i++) {
+		const uint32_t w = __builtin_amdgcn_alignbit(d[i + 1], d[i], sh);
+		const uint32_t n = have > 32u * (uint32_t)i ? have - 32u * (uint32_t)i : 0u;
+		c += (uint32_t)__popc(w & (n >= 32u ? 0xffffffffu : ((1u << n) - 1u)));
+	}
+	return c;
+}
+
+template <typename U>
+__global__ __launch_bounds__(kWorkgroup) void k_gather_c(const adac_segment_desc *__restrict__ descs,
+                                                         const TileRef *__restrict__ tiles,
+                                                         const uint64_t *__restrict__ words,
+                                                         const uint64_t *__restrict__ bitmap, uint32_t last_dword,
+                                                         const uint64_t *__restrict__ tile_off, U *__restrict__ out,
+                                                         uint64_t *__restrict__ out_ids, int nt) {
+	constexpr int TILE = kTileBytes / (int)sizeof(U);
+	constexpr int K = 16 / (int)sizeof(U);
+	constexpr int RUN = 64 * K;                    // rows one wave decodes per round: 1 KiB of values
+	constexpr int WORDS = TILE / 64;               // bitmap words of a tile: 32 / 64 / 128 / 256
+	constexpr int WPL = WORDS > 64 ? WORDS / 64 : 1; // ... per lane in the offsets pass
+	constexpr int LANES_PER_RUN = (RUN / 64) / WPL;  // lanes whose words make up one run: 2 / 4 / 4 / 4
+	__shared__ uint4 lds[kTileBytes / 16 + 2];
+	__shared__ uint4 wbuf_all[kWorkgroup / 64][65];                 // per wave: 64 units + one for the phase
+	__shared__ uint32_t wid_all[kWorkgroup / 64][RUN / 2 + 1];      // per wave: row numbers inside the tile (u16 pairs)
+	const uint64_t slot0 = tile_off[blockIdx.x]; // (asked for first: a round trip nothing else waits behind)
+	const TileCtx t = resolve_tile<TILE>(descs, tiles);
+	const uint32_t bit0 = stage_packed(words + t.d.word_off, t.first, t.n, t.d.width, lds);
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const uint32_t *__restrict__ bm32 = reinterpret_cast<const uint32_t *>(bitmap);
+	// selected rows before each run of the tile: inclusive scan over the lanes' words
+	uint32_t mine = 0;
+	{
+		const uint32_t row = lane * (uint32_t)WPL * 64u; // the lane's words are consecutive: one window of WPL words
+		const uint32_t rest = row < t.n ? t.n - row : 0u;
+		mine = bitmap_popc<WPL>(bm32, last_dword, t.elem0 + row, rest < 64u * WPL ? rest : 64u * WPL);
+	}
+	const uint32_t run_incl = wave_inclusive_sum<uint32_t>(mine);
+	const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)run_incl, 63);
+	// this lane's chunks (chunk r * 256 + thread of round r, the map of both decode forms): their selection bits and
+	// the rows selected before them inside the wave's run — bitmap loads and DPP chains of all four rounds in flight
+	// together and behind the staging loads, nothing but LDS work is left between the barrier and the stores
+	static_assert(TILE / (kWorkgroup * K) == 4, "four decode rounds per tile");
+	// (named scalars captured by value, not arrays: indexed by the round inside the sink an array went to scratch memory)
+	uint32_t pk0, pk1, pk2, pk3;     // bits | rows before << 16
+	uint32_t tot0, tot1, tot2, tot3; // selected rows of the run (uniform)
+#define ADAC_ROUND_BITS(PK, R)                                                                                         \
+	{                                                                                                                  \
+		const uint32_t base = ((uint32_t)(R) * kWorkgroup + threadIdx.x) * (uint32_t)K;                                \
+		const uint32_t rows_here = base < t.n ? (t.n - base < (uint32_t)K ? t.n - base : (uint32_t)K) : 0u;            \
+		PK = bitmap_bits32(bm32, last_dword, t.elem0 + base) & ((1u << rows_here) - 1u);                              \
+	}
+#define ADAC_ROUND_SCAN(PK, TOT)                                                                                       \
+	{                                                                                                                  \
+		const uint32_t cnt = (uint32_t)__popc(PK);                                                                     \
+		const uint32_t incl = wave_inclusive_sum<uint32_t>(cnt);                                                       \
+		TOT = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);                                                      \
+		PK |= (incl - cnt) << 16;                                                                                      \
+	}
+	ADAC_ROUND_BITS(pk0, 0) ADAC_ROUND_BITS(pk1, 1) ADAC_ROUND_BITS(pk2, 2) ADAC_ROUND_BITS(pk3, 3)
+	ADAC_ROUND_SCAN(pk0, tot0) ADAC_ROUND_SCAN(pk1, tot1) ADAC_ROUND_SCAN(pk2, tot2) ADAC_ROUND_SCAN(pk3, tot3)
+#undef ADAC_ROUND_BITS
+#undef ADAC_ROUND_SCAN
+	__syncthreads();
+	if (total == 0) return; // nothing selected in this tile (uniform): no decode at all
+	U *const wb = reinterpret_cast<U *>(wbuf_all[wave]);
+	uint16_t *const wi = reinterpret_cast<uint16_t *>(wid_all[wave]);
+	const uint64_t elem0 = t.elem0;
+	uint4 *const wunits = wbuf_all[wave];
+	const uint32_t *const widw = wid_all[wave];
+	auto sink = [=](int32_t base, const U *v, bool full) __attribute__((always_inline)) { // align 0: base = chunk * K; all 64 lanes of the wave are here
+		const uint32_t ubase = (uint32_t)base;
+		const uint32_t round = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ubase / (uint32_t)(K * kWorkgroup))); // uniform
+		// (the four candidates pass through an empty asm first: selected straight from the closure the compiler turned
+		// the chain into ONE load at a computed address and kept the whole closure in scratch memory)
+		uint32_t a0 = pk0, a1 = pk1, a2 = pk2, a3 = pk3, b0 = tot0, b1 = tot1, b2 = tot2, b3 = tot3;
+		asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+s"(b0), "+s"(b1), "+s"(b2), "+s"(b3));
+		uint32_t mine_pk = a0, tot = b0;
+		if (round == 1u) mine_pk = a1, tot = b1;
+		if (round == 2u) mine_pk = a2, tot = b2;
+		if (round == 3u) mine_pk = a3, tot = b3;
+		if (tot == 0u) return; // uniform: nothing selected in this run
+		const uint32_t bits = mine_pk & 0xffffu;
+		const uint32_t run = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ubase / (uint32_t)K)) >> 6; // uniform
+		const uint32_t before = run ? (uint32_t)__builtin_amdgcn_readlane((int)run_incl, (int)(run * LANES_PER_RUN - 1u)) : 0u;
+		const uint64_t slot = slot0 + before;
+		U *const g_out = out + slot;
+		if constexpr (sizeof(U) >= 4) {
+			// 4- and 8-byte types: one element per lane and store (a wave writes 256 / 512 contiguous bytes), no phase
+			// and no edge cases — the unit form below executed 490 vector instructions per wave against k_unpack's 100
+			// and kept the vector unit 48 % busy (SQ counters, profiles/r03_gather_compaction.json)
+			uint32_t p = mine_pk >> 16;
+#pragma unroll
+			for (int j = 0; j < K; j++) {
+				if ((bits >> j) & 1u) {
+					wb[p] = v[j];
+					if (out_ids) wi[p] = (uint16_t)(ubase + (uint32_t)j);
+					p++;
+				}
+			}
+			__builtin_amdgcn_wave_barrier();
+			for (uint32_t i = lane; i < tot; i += 64u) {
+				if (nt) {
+					__builtin_nontemporal_store(wb[i], g_out + i);
+				} else {
+					g_out[i] = wb[i];
+				}
+			}
+			if (out_ids) {
+				uint64_t *const g_ids = out_ids + slot;
+				for (uint32_t i = lane; i < tot; i += 64u) {
+					const uint64_t id = elem0 + wi[i];
+					if (nt) {
+						__builtin_nontemporal_store(id, g_ids + i);
+					} else {
+						g_ids[i] = id;
+					}
+				}
+			}
+			__builtin_amdgcn_wave_barrier();
+			return;
+		}
+		const uint32_t pe = (uint32_t)((reinterpret_cast<uintptr_t>(g_out) & 15u) / sizeof(U)); // uniform: phase, in elements
+		const uint32_t pid = (uint32_t)((reinterpret_cast<uintptr_t>(out_ids + slot) >> 3) & 1u);
+		// compaction: the wave's selected rows, in row order, at the output's 16-byte phase
+		uint32_t p = mine_pk >> 16;
+#pragma unroll
+		for (int j = 0; j < K; j++) {
+			if ((bits >> j) & 1u) {
+				wb[pe + p] = v[j];
+				if (out_ids) wi[pid + p] = (uint16_t)(ubase + (uint32_t)j);
+				p++;
+			}
+		}
+		__builtin_amdgcn_wave_barrier();
+		// values: unit u = wb[u K .. u K + K) = elements u K - pe ... of the run
+		const uint32_t nunits = (pe + tot + (uint32_t)K - 1u) / (uint32_t)K; // <= 65
+		for (uint32_t u = lane; u < nunits; u += 64u) {
+			const uint4 q = wunits[u];
+			const int32_t e0 = (int32_t)(u * (uint32_t)K) - (int32_t)pe;
+			U *const g = g_out + e0;
+			if (e0 >= 0 && (uint32_t)e0 + (uint32_t)K <= tot) {
+				typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+				const v4u qq = {q.x, q.y, q.z, q.w};
+				if (nt) {
+					__builtin_nontemporal_store(qq, reinterpret_cast<v4u *>(g));
+				} else {
+					*reinterpret_cast<v4u *>(g) = qq;
+				}
+			} else {
+				U e[K];
+				__builtin_memcpy(e, &q, 16);
+#pragma unroll
+				for (int j = 0; j < K; j++) {
+					if ((uint32_t)(e0 + j) < tot) g[j] = e[j];
+				}
+			}
+		}
+		if (out_ids) { // ids: unit u = the ids of elements 2 u - pid, 2 u + 1 - pid
+			uint64_t *const g_ids = out_ids + slot;
+			const uint32_t nid = (pid + tot + 1u) >> 1;
+			for (uint32_t u = lane; u < nid; u += 64u) {
+				const uint32_t two = widw[u];
+				const int32_t e0 = (int32_t)(2u * u) - (int32_t)pid;
+				const uint64_t id0 = elem0 + (two & 0xffffu), id1 = elem0 + (two >> 16);
+				const bool v0 = e0 >= 0, v1 = (uint32_t)(e0 + 1) < tot;
+				if (v0 && v1) {
+					typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+					const v4u qq = {(uint32_t)id0, (uint32_t)(id0 >> 32), (uint32_t)id1, (uint32_t)(id1 >> 32)};
+					if (nt) {
+						__builtin_nontemporal_store(qq, reinterpret_cast<v4u *>(g_ids + e0));
+					} else {
+						*reinterpret_cast<v4u *>(g_ids + e0) = qq;
+					}
+				} else if (v0) {
+					g_ids[e0] = id0;
+				} else if (v1) {
+					g_ids[e0 + 1] = id1;
+				}
+			}
+		}
+		__builtin_amdgcn_wave_barrier();
+	};
+	decode_tile<U, true>(reinterpret_cast<const uint32_t *>(lds), bit0, t.d.width, effective_add(t.d), t.n, 0u, sink);
+}

@@ -250,3 +250,69 @@ def test_select_bitmap_words_shared_by_many_groups(adac, oracle, gpu_ctx, dtype)
     check_select(adac, gpu_ctx, lay, d_words, dtype, segs, offs, span, probes)
     valid = rng.random(span) > 0.3
     check_select(adac, gpu_ctx, lay, d_words, dtype, segs, offs, span, probes[:2], valid)
+
+
+@pytest.mark.parametrize("dtype", [np.uint64, np.int32, np.uint16, np.int8])
+def test_scans_finish_their_results_inside_the_kernel(adac, oracle, gpu_ctx, dtype):
+    """Arrival cells (round 3): SUM / COUNT / selection leave every per-segment result and every bitmap word STORED by
+    the last group that contributes to it — no clearing pass before the scan, no merge kernel after it.  So: outputs
+    poisoned before every call, segments without rows in between (they have no group: cleared by the call), segments
+    of one row up to several scan groups, widths 2 and 3 (the narrow kernel) next to the common kernel's, calls
+    repeated (the cells must be back at zero), and the clearing-pass form (scan_cells = 0) as the cross-check."""
+    dtype = np.dtype(dtype)
+    rng = np.random.default_rng(977 + dtype.itemsize)
+    tile = adac.tile_values(dtype)
+    counts = [0, 1, 1, 0, 33, 2, 5 * tile + 3, 0, 0, 31, 14 * tile, 1, 64, 17 * tile + 1, 0, 3, 2 * tile, 7, 0]
+    bits = [1, 1, 2, 1, 3, 2, 2, 1, 1, 3, 7, 1, 5, 3, 1, 2, 6, 2, 1]
+    segs = [make_values(rng, dtype, n, min(b, 8 * dtype.itemsize)) if n else np.zeros(0, dtype) for n, b in zip(counts, bits)]
+    counts = np.array(counts, dtype=np.uint32)
+    lay, d_words, _, _, _ = run_encode_decode(adac, oracle, gpu_ctx, dtype, counts, segs)
+    offs = np.concatenate([[0], np.cumsum(counts[:-1])]).astype(np.int64).tolist()
+    span = int(counts.sum())
+    nw = (span + 63) // 64
+    nseg = len(segs)
+    poison = np.full(nseg, 0xDEADBEEFDEADBEEF, dtype=np.uint64)
+    d_res = gpu_ctx.alloc(nseg * 8)
+    d_bm = gpu_ctx.alloc(nw * 8 + 8)
+    info = np.iinfo(dtype)
+    big = segs[int(np.argmax(counts))]
+    probes = [(int(info.min), int(info.max)), (int(np.median(big)), int(info.max)), (int(big[0]), int(big[0]))]
+    try:
+        for cells in (1, 0, 1):
+            adac.set_tuning("scan_cells", cells)
+            for group in (0, 3):
+                adac.set_tuning("scan_tiles_per_wg", group)
+                for rep in range(3):
+                    d_res.upload(poison)
+                    lay.scan_sum(d_words, d_res)
+                    assert d_res.download(np.uint64, nseg).tolist() == [wide_sum(v) for v in segs], (cells, group, rep)
+                    # the same with every other group sending the halves of its sum the other way round, so that two
+                    # parties of a segment complete one word each and meet at the third (arrive_sum's rare branch)
+                    adac.set_tuning("sel_debug", 7)
+                    d_res.upload(poison)
+                    lay.scan_sum(d_words, d_res)
+                    adac.set_tuning("sel_debug", 0)
+                    assert d_res.download(np.uint64, nseg).tolist() == [wide_sum(v) for v in segs], (cells, group, rep, "swapped")
+                    for lo, hi in probes:
+                        exp = expected_bitmap(segs, offs, span, lo, hi)
+                        want = [int(exp[o:o + len(v)].sum()) for v, o in zip(segs, offs)]
+                        d_res.upload(poison)
+                        lay.scan_count_between(d_words, bit_pattern(lo, dtype), bit_pattern(hi, dtype), d_res)
+                        assert d_res.download(np.uint64, nseg).tolist() == want, (cells, group, rep, lo, hi)
+                        d_res.upload(poison)
+                        d_bm.upload(np.full(nw + 1, 0xDEADBEEFDEADBEEF, dtype=np.uint64))
+                        lay.scan_select_between(d_words, bit_pattern(lo, dtype), bit_pattern(hi, dtype), d_bm, d_res)
+                        assert d_res.download(np.uint64, nseg).tolist() == want, (cells, group, rep, lo, hi)
+                        got = d_bm.download(np.uint64, nw + 1)
+                        assert int(got[nw]) == 0xDEADBEEFDEADBEEF
+                        allbits = np.unpackbits(got[:nw].view(np.uint8), bitorder="little")
+                        assert np.array_equal(allbits[:span].astype(bool), exp), (cells, group, rep, lo, hi)
+                        assert not allbits[span:].any()
+                    # an empty range stores zeros everywhere
+                    d_res.upload(poison)
+                    lay.scan_count_between(d_words, bit_pattern(5, dtype), bit_pattern(4, dtype), d_res)
+                    assert not d_res.download(np.uint64, nseg).any()
+    finally:
+        adac.set_tuning("scan_cells", 1)
+        adac.set_tuning("sel_debug", 0)
+        adac.set_tuning("scan_tiles_per_wg", 0)

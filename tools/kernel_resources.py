@@ -31,7 +31,7 @@ FIELDS = {
 # the kernels whose registers / occupancy decide a measured throughput; matched as prefixes of the
 # short name below
 BUDGETED = ("k_unpack<", "k_unpack_jobs<", "k_scan_agg<", "k_encode_1p<", "k_repack_g<", "k_analyze_packed_g<",
-            "k_group_sum", "k_gather<", "k_pack<", "k_analyze<", "k_bp_unpack<")
+            "k_group_sum", "k_gather<", "k_gather_c<", "k_pack<", "k_analyze<", "k_bp_unpack<")
 
 
 def short_name(demangled):
@@ -79,7 +79,8 @@ def budgeted(table):
 
 
 def main():
-    table = parse()
+    # --remarks <file>: the remarks of another build (tools/snapbuild.sh keeps them next to its library)
+    table = parse(sys.argv[sys.argv.index("--remarks") + 1]) if "--remarks" in sys.argv else parse()
     if "--write-budget" in sys.argv:
         out = {k: {f: v[f] for f in ("vgprs", "agprs", "vgpr_spills", "sgpr_spills", "scratch", "occupancy", "lds")}
                for k, v in budgeted(table).items()}

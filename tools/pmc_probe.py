@@ -3,7 +3,7 @@
 `rocprofv3 --pmc ...` (or --kernel-trace --stats) can be attached to exactly those kernels.
 
 usage: python3 tools/pmc_probe.py <ops> <cases> [rows] [reps]
-  ops    comma list of: unpack, sum, count, select, encode, pack, repack, analyze, groupsum (SUM / COUNT GROUP BY a
+  ops    comma list of: unpack, sum, count, select, gather, encode, pack, repack, analyze, groupsum (SUM / COUNT GROUP BY a
          6-valued uint8 code column, the Q1 shape)
   cases  comma list of <dtype>:<width>, e.g. u64:13,u64:16,u32:8
 Prints one JSON object with the HIP-event launch times (ms) per case and op.
@@ -67,6 +67,14 @@ def main():
             timed("select", lambda: lay.scan_select_between(d_words, 0, 2 ** (w - 1), d_bm, d_res))
             rec["select_read_GBps"] = rd / (rec["ms"]["select"] * 1e-3) / 1e9
             del d_bm
+        if "gather" in ops:  # scan-with-selection at 50 % selectivity: values + element ids of the selected rows
+            d_bm = ctx.alloc((rows + 63) // 64 * 8 + 8)
+            lay.scan_select_between(d_words, 0, 2 ** (w - 1) - 1, d_bm, d_res)
+            nsel = int((vals < 2 ** (w - 1)).sum())
+            d_go, d_gi = ctx.alloc((nsel + 16) * dtype.itemsize), ctx.alloc((nsel + 16) * 8)
+            timed("gather", lambda: lay.unpack_selected(d_words, d_bm, d_go, d_gi, False))
+            rec["gather_traffic_GBps"] = (rd + rows // 4 + nsel * (dtype.itemsize + 8)) / (rec["ms"]["gather"] * 1e-3) / 1e9
+            del d_bm, d_go, d_gi
         if "groupsum" in ops:
             code = rng.choice(6, size=rows, p=[.2466, .2534, .0004, .2500, .2490, .0006]).astype(np.uint8)
             klay = adac.Layout(ctx, np.uint8, counts)
