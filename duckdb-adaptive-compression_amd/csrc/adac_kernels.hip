@@ -728,14 +728,19 @@ struct ChunkSum {
 };
 
 // `nbits` (<= 32) mask bits starting at element index e: bit j of the result = element e + j; bits past nbits are
-// unspecified.  The second word is read only when the wanted bits reach into it, so a mask of exactly
-// ceil(span / 64) words is never over-read as long as nbits is clipped to the rows that exist.
+// unspecified (0 when nbits is 0: e may then lie past the mask).  BRANCH-FREE: the second word is the one that holds the
+// LAST wanted bit — always inside a mask of exactly ceil(span / 64) words, and the first word again when the bits do
+// not reach into the next one — so both loads are unconditional and in flight together.  (Round 3: with the second
+// load under `if (sh + nbits > 64)` every call compiled to a branch with its own s_waitcnt and a lane's windows went
+// out one round trip after the other: k_gather_c 0.31 -> 0.26 ms at C2, profiles/r03_gather_compaction.json.)
 __device__ __forceinline__ uint32_t validity_window(const uint64_t *__restrict__ validity, uint64_t e, uint32_t nbits) {
-	if (nbits == 0u) return 0u; // nothing wanted: e may lie past the mask
-	const uint32_t sh = (uint32_t)(e & 63);
-	uint64_t wnd = validity[e >> 6] >> sh;
-	if (sh + nbits > 64u) wnd |= validity[(e >> 6) + 1] << (64 - sh);
-	return (uint32_t)wnd;
+	const uint64_t end = e + nbits;
+	const uint64_t last = end - (end != 0ull ? 1ull : 0ull); // the last wanted bit (the bit before e if none is wanted)
+	const uint64_t first = e < last ? e : last;
+	const uint32_t sh = (uint32_t)(first & 63);
+	const uint64_t w0 = validity[first >> 6], w1 = validity[last >> 6];
+	const uint64_t wnd = (w0 >> sh) | ((w1 << 1) << (63u - sh)); // w1 == w0 when no bit of the next word is wanted
+	return nbits ? (uint32_t)wnd : 0u;
 }
 
 // hits = 2 * hits + (d <= span).  The compare lands in VCC and is consumed as the carry-in of ONE add: two vector
@@ -773,12 +778,36 @@ __device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint
 	const uint32_t Lc = L < clast ? L : clast;
 	uint4 q = seg16[Lc];
 	uint32_t e = reinterpret_cast<const uint32_t *>(seg16 + (Lc < clast ? Lc + 1 : clast))[0];
+	// V: the two mask words that hold a chunk's rows travel with the chunk — requested a round ahead, unconditionally,
+	// word indices (relative to the segment's first word, 32 bits) clamped to the word of the run's last row.  Looked
+	// up inside the loop after the walk, the mask cost the masked scans 15 - 40 % (u64 w 8: SUM 5.07 -> 3.16 TB/s).
+	const uint64_t *__restrict__ vseg = V ? validity + (d.val_off >> 6) : nullptr;
+	const uint32_t vsh0 = (uint32_t)(d.val_off & 63u);
+	const uint32_t vend = (vsh0 + r1 - 1u) >> 6;
+	auto mask_words = [&](uint32_t Lx, uint64_t &m0, uint64_t &m1) {
+		const uint32_t ix0 = (128u * Lx + (W - 1)) / W;
+		const uint32_t wi = (vsh0 + (ix0 < r1 ? ix0 : r1)) >> 6;
+		m0 = vseg[wi < vend ? wi : vend];
+		m1 = vseg[wi + 1u < vend ? wi + 1u : vend];
+	};
+	// the 64 mask bits from row `at` on (bits past the run's last row are unspecified)
+	auto mask_window = [&](uint64_t m0, uint64_t m1, uint32_t at) -> uint64_t {
+		const uint32_t sh = (vsh0 + at) & 63u;
+		return (m0 >> sh) | ((m1 << 1) << (63u - sh));
+	};
+	uint64_t vm0 = 0, vm1 = 0;
+	if (V) mask_words(Lc, vm0, vm1);
 	constexpr uint32_t adv = STRIDE;
 	uint32_t wave_count = 0; // wave-uniform (scalar) COUNT accumulator; lane 0 of the wave leaves the loop last
 	for (; L < lend; L += adv) {
 		const uint32_t Lp = L + adv < clast ? L + adv : clast;
 		const uint4 qn = seg16[Lp];
 		const uint32_t en = reinterpret_cast<const uint32_t *>(seg16 + (Lp < clast ? Lp + 1 : clast))[0];
+		uint64_t vn0 = 0, vn1 = 0;
+		if (V) mask_words(Lp, vn0, vn1);
+		const uint64_t vwnd = V ? mask_window(vm0, vm1, ((128u * L + (W - 1)) / W) < r1 ? ((128u * L + (W - 1)) / W) : r1) : 0ull;
+		vm0 = vn0;
+		vm1 = vn1;
 		const uint32_t i0 = (128u * L + (W - 1)) / W; // first row starting in this chunk
 		const uint32_t o0 = i0 * W - 128u * L;        // its bit offset, < W <= 32
 		uint32_t nrm[5];
@@ -825,8 +854,8 @@ __device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint
 			hi &= n_hi >= 32u ? 0xffffffffu : ((1u << n_hi) - 1u);
 			const uint32_t at = i0 < r1 ? i0 : r1; // keeps a lane's element range inside this run
 			if (V) { // NULL rows take no part
-				lo &= validity_window(validity, d.val_off + at, n_lo);
-				hi &= validity_window(validity, d.val_off + at + 32u, n_hi);
+				lo &= (uint32_t)vwnd;
+				hi &= (uint32_t)(vwnd >> 32);
 			}
 			acc += (uint32_t)__popc(lo) + (uint32_t)__popc(hi);
 			if (OP == 3 && sel_out.debug < 2) {
@@ -847,7 +876,7 @@ __device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint
 			hits &= have >= 32u ? 0xffffffffu : ((1u << have) - 1u);
 			const uint32_t at = i0 < r1 ? i0 : r1; // keeps a lane's element range inside this run
 			// NULL rows (DuckDB validity mask over the element index space) take no part
-			if (V) hits &= validity_window(validity, d.val_off + at, have);
+			if (V) hits &= (uint32_t)vwnd;
 			acc += (uint32_t)__popc(hits);
 			if (OP == 3 && sel_out.debug < 2) sel_or(sel_out, sh0 + at, hits, have);
 			continue;
@@ -856,7 +885,7 @@ __device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint
 		uint32_t nv = 0;
 		if (V) {
 			const uint32_t have = starting < lim ? starting : lim;
-			const uint32_t vbits = validity_window(validity, d.val_off + i0, have);
+			const uint32_t vbits = (uint32_t)vwnd;
 #pragma unroll
 			for (int j = 0; j < MAXV; j++) {
 				if ((uint32_t)j < have) agg.add_if(field_of<W>(nrm, j), (vbits >> j) & 1u);

@@ -8,6 +8,7 @@ usage: python3 tools/ab_select.py <case,case,...> [rounds] [reps]     e.g. c2,u3
   AB_KNOBS="name=v;name=v|name=v"   '|' separates settings, ';' knobs inside one (default: the library's defaults)
   AB_SELECTIVITY=0.5                fraction of the value domain the predicate keeps
   AB_IDS=1                          unpack_selected with element ids (default) / 0 = values only
+  AB_VALID=0.9                      also time SUM / COUNT / selection under a validity mask with this fraction of valid rows
 """
 import importlib
 import json
@@ -28,6 +29,7 @@ def main():
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
     frac = float(os.environ.get("AB_SELECTIVITY", "0.5"))
     with_ids = os.environ.get("AB_IDS", "1") != "0"
+    valid_frac = float(os.environ.get("AB_VALID", "0"))
     settings = [dict(kv.split("=") for kv in s.split(";") if kv) for s in os.environ.get("AB_KNOBS", "").split("|")]
     ctx = adac.Context(0)
     rng = np.random.default_rng(3)
@@ -61,6 +63,12 @@ def main():
         rec = {"case": case, "rows": rows, "selected": nsel, "packed_bytes": packed, "settings": []}
         t_sel = [[] for _ in settings]
         t_gat = [[] for _ in settings]
+        t_vsum, t_vcnt, t_vsel = [[] for _ in settings], [[] for _ in settings], [[] for _ in settings]
+        d_valid = None
+        if valid_frac > 0:
+            vmask = rng.random(rows) < valid_frac
+            vb = np.packbits(vmask, bitorder="little")
+            d_valid = ctx.upload(np.concatenate([vb, np.zeros((-len(vb)) % 8 + 8, np.uint8)]).view(np.uint64))
         t_sum = [[] for _ in settings]
         t_cnt = [[] for _ in settings]
         wide = np.int64 if dtype.kind == "i" else np.uint64
@@ -86,6 +94,18 @@ def main():
                     assert np.array_equal(d_cnt.download(np.uint64, len(counts)), exp_sums), (case, st, "sums")
                     lay.scan_count_between(d_words, 0, hi, d_cnt)
                     assert np.array_equal(d_cnt.download(np.uint64, len(counts)), exp_cnts), (case, st, "counts")
+                    if d_valid is not None:
+                        ev = np.add.reduceat(np.where(vmask, vals, 0).astype(wide), starts[:-1]).astype(np.uint64)
+                        lay.scan_sum(d_words, d_cnt, d_valid)
+                        assert np.array_equal(d_cnt.download(np.uint64, len(counts)), ev), (case, st, "masked sums")
+                        ec = np.add.reduceat(((vals <= hi) & vmask).astype(np.uint64), starts[:-1])
+                        lay.scan_count_between(d_words, 0, hi, d_cnt, d_valid)
+                        assert np.array_equal(d_cnt.download(np.uint64, len(counts)), ec), (case, st, "masked counts")
+                        lay.scan_select_between(d_words, 0, hi, d_bm, d_cnt, d_valid)
+                        assert np.array_equal(d_cnt.download(np.uint64, len(counts)), ec), (case, st, "masked select counts")
+                        bm = d_bm.download(np.uint64, (rows + 63) // 64)
+                        exp = np.packbits((vals <= hi) & vmask, bitorder="little")
+                        assert np.array_equal(bm.view(np.uint8)[:len(exp)], exp), (case, st, "masked bitmap")
                     continue
                 ctx.sync()
                 ctx.timer_start()
@@ -104,10 +124,24 @@ def main():
                 for _ in range(reps):
                     lay.scan_count_between(d_words, 0, hi, d_cnt)
                 t_cnt[i].append(ctx.timer_stop() / reps)
+                if d_valid is not None:
+                    for fn, acc in ((lambda: lay.scan_sum(d_words, d_cnt, d_valid), t_vsum),
+                                    (lambda: lay.scan_count_between(d_words, 0, hi, d_cnt, d_valid), t_vcnt),
+                                    (lambda: lay.scan_select_between(d_words, 0, hi, d_bm, d_cnt, d_valid), t_vsel)):
+                        ctx.timer_start()
+                        for _ in range(reps):
+                            fn()
+                        acc[i].append(ctx.timer_stop() / reps)
         gbytes = packed + (rows + 7) // 8 * 2 + nsel * (dtype.itemsize + (8 if with_ids else 0))
         for i, st in enumerate(settings):
             ms_s, ms_g = float(np.median(t_sel[i])), float(np.median(t_gat[i]))
-            rec["settings"].append({"knobs": st, "select_ms": ms_s, "select_min_ms": float(min(t_sel[i])),
+            masked = {} if d_valid is None else {
+                "masked_sum_ms": float(np.median(t_vsum[i])), "masked_count_ms": float(np.median(t_vcnt[i])),
+                "masked_select_ms": float(np.median(t_vsel[i])),
+                "masked_sum_read_GBps": packed / float(np.median(t_vsum[i])) / 1e6,
+                "masked_count_read_GBps": packed / float(np.median(t_vcnt[i])) / 1e6,
+                "masked_select_read_GBps": packed / float(np.median(t_vsel[i])) / 1e6}
+            rec["settings"].append({**masked, "knobs": st, "select_ms": ms_s, "select_min_ms": float(min(t_sel[i])),
                                     "select_read_GBps": packed / ms_s / 1e6,
                                     "sum_ms": float(np.median(t_sum[i])), "sum_read_GBps": packed / float(np.median(t_sum[i])) / 1e6,
                                     "count_ms": float(np.median(t_cnt[i])), "count_read_GBps": packed / float(np.median(t_cnt[i])) / 1e6,

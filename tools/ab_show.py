@@ -14,5 +14,9 @@ for f in sys.argv[1:]:
                 print("    %-40s sel %.4f (%4.0f) sum %.4f (%4.0f) cnt %.4f (%4.0f) gather %.4f (%4.0f GB/s)" % (
                     k, s["select_ms"], s["select_read_GBps"], s.get("sum_ms", 0), s.get("sum_read_GBps", 0),
                     s.get("count_ms", 0), s.get("count_read_GBps", 0), s["gather_ms"], s["gather_traffic_GBps"]))
+                if "masked_sum_ms" in s:
+                    print("    %-40s masked: sum %.4f (%4.0f) cnt %.4f (%4.0f) sel %.4f (%4.0f GB/s)" % (
+                        "", s["masked_sum_ms"], s["masked_sum_read_GBps"], s["masked_count_ms"], s["masked_count_read_GBps"],
+                        s["masked_select_ms"], s["masked_select_read_GBps"]))
             else:
                 print("    %-40s median %.4f min %.4f max %.4f ms" % (k, s["median_ms"], s["min_ms"], s["max_ms"]))
