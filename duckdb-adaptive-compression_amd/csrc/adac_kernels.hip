@@ -728,12 +728,23 @@ struct ChunkSum {
 };
 
 // `nbits` (<= 32) mask bits starting at element index e: bit j of the result = element e + j; bits past nbits are
-// unspecified (0 when nbits is 0: e may then lie past the mask).  BRANCH-FREE: the second word is the one that holds the
-// LAST wanted bit — always inside a mask of exactly ceil(span / 64) words, and the first word again when the bits do
-// not reach into the next one — so both loads are unconditional and in flight together.  (Round 3: with the second
-// load under `if (sh + nbits > 64)` every call compiled to a branch with its own s_waitcnt and a lane's windows went
-// out one round trip after the other: k_gather_c 0.31 -> 0.26 ms at C2, profiles/r03_gather_compaction.json.)
+// unspecified.  The second word is read only when the wanted bits reach into it, so a mask of exactly
+// ceil(span / 64) words is never over-read as long as nbits is clipped to the rows that exist.
+// (This form costs a branch and a wait of its own per call; it is kept where the mask is an OPTION of a kernel whose
+// hot path runs without one — re-compaction, k_analyze_packed: with the branch-free form below k_repack_g<u8> went
+// from 89 to 97 VGPRs and lost an occupancy step and 6 - 10 % on columns that have no mask at all.)
 __device__ __forceinline__ uint32_t validity_window(const uint64_t *__restrict__ validity, uint64_t e, uint32_t nbits) {
+	if (nbits == 0u) return 0u; // nothing wanted: e may lie past the mask
+	const uint32_t sh = (uint32_t)(e & 63);
+	uint64_t wnd = validity[e >> 6] >> sh;
+	if (sh + nbits > 64u) wnd |= validity[(e >> 6) + 1] << (64 - sh);
+	return (uint32_t)wnd;
+}
+// The same, BRANCH-FREE, for kernels that always read a mask: the second word is the one that holds the LAST wanted
+// bit — always inside the mask, and the first word again when the bits do not reach into the next one — so both loads
+// are unconditional and in flight together.  (Round 3: with the conditional form a lane's windows went out one round
+// trip after the other: k_gather_c 0.31 -> 0.26 ms at C2, profiles/r03_gather_compaction.json.)
+__device__ __forceinline__ uint32_t validity_window_pair(const uint64_t *__restrict__ validity, uint64_t e, uint32_t nbits) {
 	const uint64_t end = e + nbits;
 	const uint64_t last = end - (end != 0ull ? 1ull : 0ull); // the last wanted bit (the bit before e if none is wanted)
 	const uint64_t first = e < last ? e : last;
@@ -1057,7 +1068,7 @@ __global__ __launch_bounds__(kWorkgroup, NARROW ? 4 : 6) void k_scan_agg(
 			auto sink = [&](int32_t base, const U *vals, bool full) {
 				constexpr int KK = 16 / (int)sizeof(U);
 				const uint32_t rows_here = full || n - (uint32_t)base >= (uint32_t)KK ? (uint32_t)KK : n - (uint32_t)base;
-				const uint32_t vbits = V ? validity_window(validity, elem0 + (uint32_t)base, rows_here) : 0xffffffffu;
+				const uint32_t vbits = V ? validity_window_pair(validity, elem0 + (uint32_t)base, rows_here) : 0xffffffffu;
 				if (OP == 3) { // decode_run walks with align 0: base >= 0, lanes ascending
 					uint32_t hits = 0;
 #pragma unroll

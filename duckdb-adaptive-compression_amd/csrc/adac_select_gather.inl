@@ -27,7 +27,7 @@ __global__ __launch_bounds__(kWorkgroup) void k_tile_popc(const adac_segment_des
 	for (uint32_t i = (threadIdx.x & 63u) * 32u; i < n; i += 64u * 32u) {
 		const uint32_t rest = n - i;
 		const uint32_t m = rest >= 32u ? 0xffffffffu : ((1u << rest) - 1u);
-		c += (uint32_t)__popc(validity_window(bitmap, e0 + i, rest >= 32u ? 32u : rest) & m);
+		c += (uint32_t)__popc(validity_window_pair(bitmap, e0 + i, rest >= 32u ? 32u : rest) & m);
 	}
 	c = wave_inclusive_sum<uint32_t>(c);
 	if ((threadIdx.x & 63u) == 63u) tile_cnt[t] = c;
