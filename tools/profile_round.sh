@@ -4,7 +4,7 @@
 # prescribes), then profiles/summarize.py turns them into the committed summaries.
 # Last step: tools/sweep_diff.py holds the new bench line against the PREVIOUS committed round (second argument, default:
 # the newest profiles/*_bench.json that is not this tag's) and the script FAILS LOUDLY (exit 3, after every file has
-# been written) when a cell of the 8-32-bit band lost more than 3 % after the box factor is divided out.
+# been written) when a cell of the 8-32-bit band lost more than 5 % under both normalisations of tools/sweep_diff.py.
 #   usage: bash tools/profile_round.sh <tag> [previous_bench.json]   (writes gpurun_out/<tag>/ and profiles/<tag>_*)
 set -o pipefail
 TAG=${1:-r03}

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Guard against silent throughput regressions between two bench lines (bench.py's "sweep" + headline figures).
 
-  python tools/sweep_diff.py profiles/r02i_bench.json gpurun_out/r03x/bench.json [--limit 3.0]
+  python tools/sweep_diff.py profiles/r02i_bench.json gpurun_out/r03x/bench.json [--limit 5.0]
 
 Two runs land on two different boxes, and boxes differ by 3 - 7 % across the board (the same r02i binary: fused SUM
 u64 w 8 5668 GB/s on one box, 5277 on another).  So every cell is compared twice: raw, and NORMALISED by the box
@@ -50,7 +50,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("old")
     ap.add_argument("new")
-    ap.add_argument("--limit", type=float, default=3.0, help="allowed normalised loss in percent")
+    ap.add_argument("--limit", type=float, default=5.0,
+                    help="allowed normalised loss in percent (the box factor itself is only good to +-4 %: the byte-identical "
+                         "decode kernel read -1 % raw between two rounds whose copy rates differed by +4 %)")
     a = ap.parse_args()
     old_line, new_line = json.load(open(a.old)), json.load(open(a.new))
     old, new = cells(old_line), cells(new_line)
