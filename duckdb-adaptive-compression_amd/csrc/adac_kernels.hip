@@ -2604,7 +2604,7 @@ hipError_t launch_gather_selected(hipStream_t s, uint32_t type_size, const adac_
 		hipLaunchKernelGGL(k_scan_fixup, dim3((unsigned)nblocks), dim3(kScanBlock), 0, s, d_tile_off, ntiles, d_block_tot);
 		if (g_tuning.gather_compact && bitmap_words < (1ull << 31)) { // (32-bit dword indices into the bitmap)
 			hipLaunchKernelGGL(k_gather_c<U>, dim3((unsigned)ntiles), dim3(kWorkgroup), 0, s, d_descs, d_tiles, d_words,
-			                   d_bitmap, (uint32_t)(2 * bitmap_words - 1), d_tile_off, static_cast<U *>(d_out), d_out_ids,
+			                   d_bitmap, (uint32_t)(2 * bitmap_words - 1), d_tile_cnt, d_tile_off, static_cast<U *>(d_out), d_out_ids,
 			                   g_tuning.gather_compact & 2);
 		} else {
 			hipLaunchKernelGGL(k_gather<U>, dim3((unsigned)ntiles), dim3(kWorkgroup), 0, s, d_descs, d_tiles, d_words,

@@ -193,6 +193,7 @@ __global__ __launch_bounds__(kWorkgroup) void k_gather_c(const adac_segment_desc
                                                          const TileRef *__restrict__ tiles,
                                                          const uint64_t *__restrict__ words,
                                                          const uint64_t *__restrict__ bitmap, uint32_t last_dword,
+                                                         const uint32_t *__restrict__ tile_cnt,
                                                          const uint64_t *__restrict__ tile_off, U *__restrict__ out,
                                                          uint64_t *__restrict__ out_ids, int nt) {
 	constexpr int TILE = kTileBytes / (int)sizeof(U);
@@ -205,7 +206,13 @@ __global__ __launch_bounds__(kWorkgroup) void k_gather_c(const adac_segment_desc
 	__shared__ uint4 wbuf_all[kWorkgroup / 64][65];                 // per wave: 64 units + one for the phase
 	__shared__ uint32_t wid_all[kWorkgroup / 64][RUN / 2 + 1];      // per wave: row numbers inside the tile (u16 pairs)
 	const uint64_t slot0 = tile_off[blockIdx.x]; // (asked for first: a round trip nothing else waits behind)
+	// A tile without a selected row leaves before it reads a packed byte or a bitmap word: its count (k_tile_popc's)
+	// is asked for together with the tile entry and is there a hop before the descriptor, which the staging loads
+	// need anyway — the test costs the other tiles nothing.  A clustered selection (a range of a sorted column) pays
+	// for the tiles it touches only.
+	const uint32_t selected_here = tile_cnt[blockIdx.x];
 	const TileCtx t = resolve_tile<TILE>(descs, tiles);
+	if (selected_here == 0u) return;
 	const uint32_t bit0 = stage_packed(words + t.d.word_off, t.first, t.n, t.d.width, lds);
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	const uint32_t *__restrict__ bm32 = reinterpret_cast<const uint32_t *>(bitmap);

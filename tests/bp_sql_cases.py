@@ -34,12 +34,32 @@ def build_column(case):
             v = np.array(p["values"], dtype=dtype)[i % 2]
         elif p["kind"] == "floordiv":
             v = (i // p["d"]).astype(dtype)
+        elif p["kind"] == "pow2_step":
+            v = np.array([p["sign"] * 2 ** int(k) for k in i // p["step"]], dtype=object).astype(dtype)
+        elif p["kind"] == "floordiv_mod":
+            v = ((i // p["d"]) % p["m"]).astype(dtype)
+        elif p["kind"] == "mod":
+            v = ((i % p["m"]) * p["scale"]).astype(dtype)
+        elif p["kind"] == "list":
+            v = np.array(p["values"], dtype=object).astype(dtype)
+        elif p["kind"] == "affine_u64":
+            v = np.array([(p["a"] * int(k) + p["b"]) % 2 ** 64 for k in i], dtype=object).astype(dtype)
+        elif p["kind"] == "null":
+            v = np.zeros(len(i), dtype=dtype)
         else:
             raise ValueError(p["kind"])
         vals.append(v)
-        valid.append(i % p["null_every"] != 0 if "null_every" in p else np.ones(len(i), dtype=bool))
+        if p["kind"] == "null":
+            valid.append(np.zeros(len(i), dtype=bool))
+        else:
+            valid.append(i % p["null_every"] != 0 if "null_every" in p else np.ones(len(i), dtype=bool))
     valid = np.concatenate(valid)
     return np.concatenate(vals), (None if valid.all() else valid)
+
+
+def refused(case):
+    """the file expects 'Uncompressed': the codec must decline the column under every forced mode"""
+    return any(e["op"] == "compression_is_not_bitpacking" for e in case["expect"])
 
 
 def check_expectations(case, decoded, valid, fetch=None, filter_eq=None):
@@ -51,8 +71,8 @@ def check_expectations(case, decoded, valid, fetch=None, filter_eq=None):
     as_int = [int(x) for x in live]
     for e in case["expect"]:
         op = e["op"]
-        if op == "compression_is_bitpacking":
-            continue  # asserted by the caller: the column was encodable under the forced mode
+        if op in ("compression_is_bitpacking", "compression_is_not_bitpacking"):
+            continue  # asserted by the caller: the column was (not) encodable under the forced mode
         if op == "head":
             assert [int(x) for x in decoded[e["offset"]:e["offset"] + len(e["rows"])]] == e["rows"], e
         elif op == "avg":
@@ -75,5 +95,18 @@ def check_expectations(case, decoded, valid, fetch=None, filter_eq=None):
         elif op == "rows_agg":
             r = decoded[np.array(e["rows"])]
             assert (int(r.astype(np.int64).sum()), int(r.min()), int(r.max()), len(r)) == (e["sum"], e["min"], e["max"], e["count"]), e
+        elif op == "distinct_values":
+            assert len(np.unique(live)) == e["n"], e
+        elif op == "every_group_count":
+            assert set(np.unique(live, return_counts=True)[1].tolist()) == {e["count"]}, e
+        elif op == "min_max_avg_count":
+            assert (min(as_int), max(as_int), len(as_int)) == (e["min"], e["max"], e["count"]), e
+            assert abs(sum(as_int) / len(as_int) - e["avg"]) <= 1e-9 * max(1.0, abs(e["avg"])), e
+        elif op == "avg_approx":
+            assert abs(sum(as_int) / len(as_int) - e["value"]) <= e["rel"] * abs(e["value"]), (e, sum(as_int) / len(as_int))
+        elif op == "count_rows":
+            assert len(decoded) == e["count"], e
+        elif op == "count_valid":
+            assert len(live) == e["count"], e
         else:
             raise ValueError(op)

@@ -2,7 +2,7 @@
 """Writes tests/golden/bitpacking_sql_cases.json: the data shapes and expected results of the reference's own
 sqllogictest files for the BITPACKING codec (/root/reference/test/sql/storage/compression/bitpacking/
 {bitpacking_simple,bitpacking_delta,bitpacking_constant_delta,bitpacking_nulls,bitpacking_index_fetch,
-bitpacking_filter_pushdown}.test), transcribed BY HAND as data — each entry cites the file:line it restates; nothing
+bitpacking_filter_pushdown}.test and {bitpacking_bitwidths,bitpacking_types}.test_coverage), transcribed BY HAND as data — each entry cites the file:line it restates; nothing
 is parsed from, copied out of or run in the reference.  The expected values are the ones the .test files print."""
 import json
 import os
@@ -86,6 +86,95 @@ cases.append({
                 "rows": list(range(0, 10000, 1000)) + list(range(10000, 20000, 1000)) + list(range(20000, 30000, 1000)),
                 "sum": 403370, "min": 0, "max": 39000, "count": 30}],
 })
+
+# ---- bitpacking_bitwidths.test_coverage: values that compress to every width, per type size and forced mode ----------
+BW = REF + "bitpacking_bitwidths.test_coverage"
+for ts in (8, 16, 32, 64):
+    cases.append({
+        "id": "bitwidths_unsigned_%d" % ts, "source": BW + ":20-40", "sql_type": "UINT%d" % ts, "type": "uint%d" % ts,
+        "forced_modes": modes,
+        "pieces": [{"range": [0, ts * 2048], "kind": "pow2_step", "step": 2048, "sign": 1}],   # :21  2**(i/2048)
+        "expect": [{"op": "distinct_values", "n": ts},                # :26-29  count(*) = typesize groups
+                   {"op": "every_group_count", "count": 2048}],       # :31-34  DISTINCT(c_i) = 2048
+    })
+    cases.append({
+        "id": "bitwidths_signed_neg_%d" % ts, "source": BW + ":42-54", "sql_type": "INT%d" % ts, "type": "int%d" % ts,
+        "forced_modes": modes,
+        "pieces": [{"range": [0, ts * 2048], "kind": "pow2_step", "step": 2048, "sign": -1}],  # :43  -(2**(i/2048))
+        "expect": [{"op": "distinct_values", "n": ts},                # :48-51
+                   {"op": "every_group_count", "count": 2048}],       # :53-56
+    })
+    cases.append({
+        "id": "bitwidths_signed_pos_%d" % ts, "source": BW + ":65-75", "sql_type": "INT%d" % ts, "type": "int%d" % ts,
+        "forced_modes": modes,
+        "pieces": [{"range": [0, (ts - 1) * 2048], "kind": "pow2_step", "step": 2048, "sign": 1}],  # :66
+        "expect": [{"op": "distinct_values", "n": ts - 1}],           # :71-74  (the file's next query reads test_signed_neg again)
+    })
+for sql, p in (("TINYINT", "int8"), ("SMALLINT", "int16"), ("INTEGER", "int32"), ("BIGINT", "int64"),
+               ("UTINYINT", "uint8"), ("USMALLINT", "uint16"), ("UINTEGER", "uint32"), ("UBIGINT", "uint64"),
+               ("BOOL", "uint8")):
+    c = {
+        "id": "nullpack_" + sql.lower(), "source": BW + ":100-112", "sql_type": sql, "type": p,
+        "forced_modes": ["constant"],   # the loop over the modes has ended at :98; the last PRAGMA set stays in force
+        "pieces": [{"range": [0, 12000], "kind": "floordiv_mod", "d": 3000, "m": 2}],     # :103  (i/3000)%2
+        "expect": [{"op": "avg", "value": 0.5}],                                          # :108-111
+    }
+    if sql == "BOOL":
+        c["note"] = "a BOOL is one byte holding 0 / 1 (PhysicalType::BOOL); the codec is run on it as uint8"
+    cases.append(c)
+
+# ---- bitpacking_types.test_coverage: every numeric type, and the numerical limits -------------------------------------
+TY = REF + "bitpacking_types.test_coverage"
+for sql, p, scale in phys:
+    c = {
+        "id": "types_mod3_" + sql.replace("(", "_").replace(",", "_").replace(")", ""), "source": TY + ":17-31",
+        "sql_type": sql, "type": p, "forced_modes": modes,
+        "pieces": [{"range": [0, 10000], "kind": "mod", "m": 3, "scale": scale}],         # :19  MOD(i,3)::type
+        "expect": [{"op": "min_max_avg_count", "min": 0, "max": 2 * scale, "avg": 0.9999 * scale, "count": 10000},  # :21-24
+                   {"op": "filter_eq", "key": scale, "sum": 3333 * scale, "min": scale, "max": scale, "count": 3333}],  # :26-29
+    }
+    if scale != 1:
+        c["note"] = "stored integers; a DECIMAL(w,1) value v is stored as 10 v"
+    cases.append(c)
+cases.append({
+    "id": "types_int32_full_range_is_refused", "source": TY + ":35-46", "type": "int32", "forced_modes": modes,
+    "pieces": [{"range": [0, 2], "kind": "list", "values": [-2147483648, 2147483647]}],   # :39
+    "expect": [{"op": "compression_is_not_bitpacking"}],                                  # :41-45  'Uncompressed'
+    "comment_expectation_refusal": "':37 Range too big to force bitpacking'",
+})
+for sql, p, bits in (("INT64", "int64", 64), ("INT32", "int32", 32), ("INT16", "int16", 16), ("TINYINT", "int8", 8)):
+    cases.append({
+        "id": "types_all_but_one_bit_" + p, "source": TY + ":51-75", "sql_type": sql, "type": p, "forced_modes": modes,
+        "pieces": [{"range": [0, 2], "kind": "list", "values": [-(2 ** (bits - 2)), 2 ** (bits - 2) - 1]}],   # :57
+        "expect": [{"op": "compression_is_bitpacking"},                                    # :62-71
+                   {"op": "avg", "value": -0.5}, {"op": "count_rows", "count": 2}],        # :73-76
+    })
+limits = [("uint64", "a", 3256, 5.665461940419088e+18), ("uint32", "b", 2256, 1903811655.4255319),
+          ("uint16", "c", 1256, 25716.671974522294), ("uint8", "d", 256, 127.5)]
+for p, col, live, avg in limits:
+    pieces = [{"range": [0, 256], "kind": "affine", "a": 1, "b": 0}]                                    # :84
+    pieces.append({"range": [31768, 32768], "kind": "affine", "a": 1, "b": 0} if live >= 1256
+                  else {"range": [31768, 32768], "kind": "null"})                                        # :85
+    pieces.append({"range": [4294966295, 4294967295], "kind": "affine", "a": 1, "b": 0} if live >= 2256
+                  else {"range": [4294966295, 4294967295], "kind": "null"})                              # :86
+    pieces.append({"range": [0, 1000], "kind": "affine_u64", "a": -1, "b": U64MAX} if live >= 3256
+                  else {"range": [0, 1000], "kind": "null"})                                             # :87
+    cases.append({
+        "id": "types_unsigned_limits_" + col, "source": TY + ":81-95", "type": p, "forced_modes": modes,
+        "pieces": pieces,
+        "expect": [{"op": "avg_approx", "value": avg, "rel": 1e-15},        # :92-95 (a double as the file prints it)
+                   {"op": "count_rows", "count": 3256}, {"op": "count_valid", "count": live}],
+        # the file does not look at pragma_storage_info for this table: where BitpackingAnalyze declines the column
+        # under a forced mode (a 2048-row group of NULLs only has no FOR / DELTA form: its min / max are the initial
+        # limits and their difference overflows) DuckDB stores it uncompressed and the query results hold trivially
+        "may_be_refused": True,
+    })
+cases.append({
+    "id": "types_bool_filter", "source": TY + ":97-108", "sql_type": "BOOL", "type": "uint8", "forced_modes": modes,
+    "pieces": [{"range": [0, 10000], "kind": "mod", "m": 2, "scale": 1}],                 # :101  CAST(i%2 as BOOL)
+    "expect": [{"op": "filter_eq", "key": 1, "sum": 5000, "min": 1, "max": 1, "count": 5000}],   # :106-109
+    "note": "a BOOL is one byte holding 0 / 1 (PhysicalType::BOOL); the codec is run on it as uint8",
+})
 doc = {
     "_about": "Data shapes and expected results of the reference's own sqllogictest files for the BITPACKING codec "
               "(/root/reference/test/sql/storage/compression/bitpacking/*.test), transcribed as data: inputs as piece "
@@ -95,7 +184,10 @@ doc = {
               "Written by tests/golden/make_bitpacking_sql_cases.py; no text of the .test files is kept.",
     "piece_kinds": {"affine": "value = a * i + b for i in range", "const": "value", "alternate": "values[i % 2]",
                     "floordiv": "value = i // d (integer division of BIGINT operands)",
-                    "null_every": "row is NULL when i % null_every == 0"},
+                    "null_every": "row is NULL when i % null_every == 0",
+                    "pow2_step": "value = sign * 2 ** (i // step)", "floordiv_mod": "value = (i // d) % m",
+                    "mod": "value = (i % m) * scale", "list": "values[i]", "null": "every row NULL",
+                    "affine_u64": "value = (a * i + b) mod 2**64"},
     "cases": cases,
 }
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bitpacking_sql_cases.json")

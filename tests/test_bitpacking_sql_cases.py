@@ -3,8 +3,9 @@ shapes and expected results of /root/reference/test/sql/storage/compression/bitp
 tests/golden/bitpacking_sql_cases.json.  Every case runs under each forced mode the file loops over: the column must
 be encodable ("compression = BitPacking") and scan back to the rows / aggregates the file expects.
 
-What this pins with reference-held material: the codec's round-trip semantics under every forced mode, NULL handling
-and point fetches.  What stays a restatement: the byte layout of the block images above the 32-value pack routine
+What this pins with reference-held material: the codec's round-trip semantics under every forced mode, NULL handling,
+point fetches, every bit width of every type size, the numerical limits of the types and the refusal of a column whose
+range needs the type's full width (bitpacking_bitwidths / bitpacking_types.test_coverage).  What stays a restatement: the byte layout of the block images above the 32-value pack routine
 (pinned separately against the reference's real fastpforlib, tests/golden/fastpfor_vectors.json)."""
 import numpy as np
 import pytest
@@ -18,6 +19,15 @@ def test_oracle_reproduces_the_reference_sql_expectations(case_id):
     case = next(c for c in sc.load_cases() if c["id"] == case_id)
     vals, valid = sc.build_column(case)
     for mode in case["forced_modes"]:
+        if sc.refused(case):  # the file expects 'Uncompressed': BitpackingAnalyze must decline the column
+            with pytest.raises(ValueError):
+                bp.Compressed(vals, valid, force_mode=sc.MODE_CODE[mode])
+            continue
+        if case.get("may_be_refused"):  # the file does not assert the compression of this table
+            try:
+                bp.Compressed(vals, valid, force_mode=sc.MODE_CODE[mode])
+            except ValueError:
+                continue
         comp = bp.Compressed(vals, valid, force_mode=sc.MODE_CODE[mode])  # raises when the codec cannot encode
         got = np.concatenate([comp.scan(i) for i in range(comp.nseg)])
         assert len(got) == len(vals)

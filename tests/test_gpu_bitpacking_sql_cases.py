@@ -28,6 +28,18 @@ def test_device_codec_reproduces_the_reference_sql_expectations(adac, gpu_ctx, c
     d_valid = None if valid is None else ctx.upload(pack_validity(valid))
     for mode in case["forced_modes"]:
         plan = adac.BitpackingPlan(ctx, dtype, d_vals, n, d_valid, sc.MODE_CODE[mode])
+        if sc.refused(case):                                 # the file expects 'Uncompressed'
+            assert not plan.encodable, (case_id, mode)
+            continue
+        if case.get("may_be_refused"):                       # no compression assertion in the file: agree with the oracle
+            try:
+                bp.Compressed(vals, valid, force_mode=sc.MODE_CODE[mode])
+                oracle_ok = True
+            except ValueError:
+                oracle_ok = False
+            assert plan.encodable == oracle_ok, (case_id, mode)
+            if not oracle_ok:
+                continue
         assert plan.encodable, (case_id, mode)              # "compression = BitPacking" under this forced mode
         d_blocks = ctx.alloc(max(plan.nseg, 1) * plan.BLOCK_STRIDE + 64)
         plan.write(d_vals, d_blocks, d_valid)

@@ -8,6 +8,7 @@ usage: python3 tools/ab_select.py <case,case,...> [rounds] [reps]     e.g. c2,u3
   AB_KNOBS="name=v;name=v|name=v"   '|' separates settings, ';' knobs inside one (default: the library's defaults)
   AB_SELECTIVITY=0.5                fraction of the value domain the predicate keeps
   AB_IDS=1                          unpack_selected with element ids (default) / 0 = values only
+  AB_CLUSTERED=0.1                  also time unpack_selected on a CLUSTERED selection: one contiguous run of this fraction of the rows
   AB_VALID=0.9                      also time SUM / COUNT / selection under a validity mask with this fraction of valid rows
 """
 import importlib
@@ -63,6 +64,16 @@ def main():
         rec = {"case": case, "rows": rows, "selected": nsel, "packed_bytes": packed, "settings": []}
         t_sel = [[] for _ in settings]
         t_gat = [[] for _ in settings]
+        t_clu = [[] for _ in settings]
+        clustered = float(os.environ.get("AB_CLUSTERED", "0"))
+        d_cbm = None
+        if clustered > 0:
+            c_lo, c_hi = int(rows * (0.5 - clustered / 2)), int(rows * (0.5 + clustered / 2))
+            cm = np.zeros(rows, dtype=bool)
+            cm[c_lo:c_hi] = True
+            cb = np.packbits(cm, bitorder="little")
+            d_cbm = ctx.upload(np.concatenate([cb, np.zeros((-len(cb)) % 8 + 8, np.uint8)]).view(np.uint64))
+            del cm, cb
         t_vsum, t_vcnt, t_vsel = [[] for _ in settings], [[] for _ in settings], [[] for _ in settings]
         d_valid = None
         if valid_frac > 0:
@@ -90,6 +101,11 @@ def main():
                     if with_ids:
                         assert np.array_equal(d_ids.download(np.uint64, nsel), keep.astype(np.uint64)), (case, st, "ids")
                     assert np.array_equal(d_cnt.download(np.uint64, len(counts)), exp_cnts), (case, st, "select counts")
+                    if d_cbm is not None and c_hi - c_lo <= nsel:
+                        assert lay.unpack_selected(d_words, d_cbm, d_out, d_ids) == c_hi - c_lo
+                        assert np.array_equal(d_out.download(dtype, c_hi - c_lo), vals[c_lo:c_hi]), (case, st, "clustered values")
+                        if with_ids:
+                            assert np.array_equal(d_ids.download(np.uint64, c_hi - c_lo), np.arange(c_lo, c_hi, dtype=np.uint64))
                     lay.scan_sum(d_words, d_cnt)
                     assert np.array_equal(d_cnt.download(np.uint64, len(counts)), exp_sums), (case, st, "sums")
                     lay.scan_count_between(d_words, 0, hi, d_cnt)
@@ -116,6 +132,11 @@ def main():
                 for _ in range(reps):
                     lay.unpack_selected(d_words, d_bm, d_out, d_ids, False)
                 t_gat[i].append(ctx.timer_stop() / reps)
+                if d_cbm is not None and c_hi - c_lo <= nsel:
+                    ctx.timer_start()
+                    for _ in range(reps):
+                        lay.unpack_selected(d_words, d_cbm, d_out, d_ids, False)
+                    t_clu[i].append(ctx.timer_stop() / reps)
                 ctx.timer_start()
                 for _ in range(reps):
                     lay.scan_sum(d_words, d_cnt)
@@ -141,6 +162,9 @@ def main():
                 "masked_sum_read_GBps": packed / float(np.median(t_vsum[i])) / 1e6,
                 "masked_count_read_GBps": packed / float(np.median(t_vcnt[i])) / 1e6,
                 "masked_select_read_GBps": packed / float(np.median(t_vsel[i])) / 1e6}
+            if t_clu[i]:
+                masked["clustered_gather_ms"] = float(np.median(t_clu[i]))
+                masked["clustered_fraction"] = clustered
             rec["settings"].append({**masked, "knobs": st, "select_ms": ms_s, "select_min_ms": float(min(t_sel[i])),
                                     "select_read_GBps": packed / ms_s / 1e6,
                                     "sum_ms": float(np.median(t_sum[i])), "sum_read_GBps": packed / float(np.median(t_sum[i])) / 1e6,

@@ -14,6 +14,8 @@ for f in sys.argv[1:]:
                 print("    %-40s sel %.4f (%4.0f) sum %.4f (%4.0f) cnt %.4f (%4.0f) gather %.4f (%4.0f GB/s)" % (
                     k, s["select_ms"], s["select_read_GBps"], s.get("sum_ms", 0), s.get("sum_read_GBps", 0),
                     s.get("count_ms", 0), s.get("count_read_GBps", 0), s["gather_ms"], s["gather_traffic_GBps"]))
+                if "clustered_gather_ms" in s:
+                    print("    %-40s clustered %.0f %%: gather %.4f ms" % ("", 100 * s["clustered_fraction"], s["clustered_gather_ms"]))
                 if "masked_sum_ms" in s:
                     print("    %-40s masked: sum %.4f (%4.0f) cnt %.4f (%4.0f) sel %.4f (%4.0f GB/s)" % (
                         "", s["masked_sum_ms"], s["masked_sum_read_GBps"], s["masked_count_ms"], s["masked_count_read_GBps"],
