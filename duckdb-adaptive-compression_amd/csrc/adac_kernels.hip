@@ -711,16 +711,14 @@ struct ChunkSum {
 	static constexpr bool kFields32 = ((uint64_t)MAXV << W) <= 0xffffffffull; // MAXV fields fit a u32 sum
 	uint32_t p32 = 0;
 	uint64_t p64 = 0;
-	uint32_t nvalid = 0; // rows aggregated by add_if
+	uint32_t nvalid = 0; // rows aggregated by add_masked
 	__device__ __forceinline__ void add(uint32_t f) {
 		if (kFields32) p32 += f; else p64 += f;
 	}
-	__device__ __forceinline__ void add_if(uint32_t f, uint32_t valid_bit) {
-		const uint32_t m = 0u - valid_bit;
-		nvalid += valid_bit;
-		if (kFields32) p32 += f & m; else p64 += f & m;
+	__device__ __forceinline__ void add_masked(uint32_t f, uint32_t all_ones_if_valid) { // the caller sets nvalid
+		if (kFields32) p32 += f & all_ones_if_valid; else p64 += f & all_ones_if_valid;
 	}
-	// rows: the number of rows aggregated with add(); rows added with add_if() are counted in nvalid.
+	// rows: the number of rows aggregated with add(); rows added with add_masked() are counted in nvalid.
 	// SUM is linear on the segments this path takes: sum(value64) = sum(fields) + rows * add64.
 	__device__ __forceinline__ uint64_t total(uint32_t rows, uint64_t add64) const {
 		return (uint64_t)p32 + p64 + (uint64_t)(rows + nvalid) * add64;
@@ -895,12 +893,14 @@ __device__ __forceinline__ void scan_run_w(const uint4 *__restrict__ seg16, uint
 		ChunkSum<W> agg;
 		uint32_t nv = 0;
 		if (V) {
+			// rows that exist AND are valid, as one mask: a field then costs its extract, ONE signed bit-field extract
+			// (0 / -1 from the row's bit), an AND and an add; the rows are counted once per chunk (v_bcnt).  (Until round
+			// 3: a row test, the bit, its negation, a count and the masked add per field — six to eight instructions.)
 			const uint32_t have = starting < lim ? starting : lim;
-			const uint32_t vbits = (uint32_t)vwnd;
+			const uint32_t vb = (uint32_t)vwnd & (have >= 32u ? 0xffffffffu : ((1u << have) - 1u));
 #pragma unroll
-			for (int j = 0; j < MAXV; j++) {
-				if ((uint32_t)j < have) agg.add_if(field_of<W>(nrm, j), (vbits >> j) & 1u);
-			}
+			for (int j = 0; j < MAXV; j++) agg.add_masked(field_of<W>(nrm, j), (uint32_t)__builtin_amdgcn_sbfe((int)vb, j, 1));
+			agg.nvalid = (uint32_t)__popc(vb);
 		} else if (starting <= lim) { // interior chunk: only the last slot may be absent
 			nv = starting;
 #pragma unroll
