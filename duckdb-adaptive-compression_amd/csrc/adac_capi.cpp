@@ -74,6 +74,8 @@ struct adac_layout {
 	uint64_t ngroups = 0;
 	int groups_tiles = 0;
 	bool groups_dirty = true;
+	adac::TileRec *d_tile_recs = nullptr; // the tiles with their segments' current descriptors folded in (decode side)
+	bool tile_recs_dirty = true;
 	// the groups of segments at widths 2 and 3, which a scan kernel of their own takes (k_scan_agg<.., NARROW>): the
 	// expansion lists them on the device and their number comes back through a page-locked word; the first scan after
 	// an expansion waits for that copy (it would wait for the same stream work in its own launch anyway)
@@ -344,6 +346,7 @@ extern "C" int adac_set_tuning(const char *name, int value) {
 	else if (n == "encode_placement") adac::g_tuning.encode_placement = value;
 	else if (n == "encode_publish_ahead") adac::g_tuning.encode_publish_ahead = value;
 	else if (n == "scan_cells") adac::g_tuning.scan_cells = value;
+	else if (n == "tile_records") adac::g_tuning.tile_records = value;
 	else if (n == "gather_compact") adac::g_tuning.gather_compact = value;
 	else if (n == "group_sum_wide") adac::g_tuning.group_sum_wide = value;
 	else if (n == "group_sum_rw") adac::g_tuning.group_sum_rw = value;
@@ -582,6 +585,7 @@ extern "C" void adac_layout_destroy(adac_layout *l) {
 	if (l->d_scan_state) (void)hipFree(l->d_scan_state);
 	if (l->d_group_partial) (void)hipFree(l->d_group_partial);
 	if (l->d_sel_edges) (void)hipFree(l->d_sel_edges);
+	if (l->d_tile_recs) (void)hipFree(l->d_tile_recs);
 	if (l->d_res_cells) (void)hipFree(l->d_res_cells);
 	if (l->d_edge_cells) (void)hipFree(l->d_edge_cells);
 	adac_ctx *c = l->ctx;
@@ -644,8 +648,22 @@ static adac_status expand_groups(adac_layout *l) {
 	return ADAC_OK;
 }
 
+// the decode-side tile records, rebuilt (in stream order) when descriptors changed since they were last built
+static adac_status tile_records(adac_layout *l, const adac::TileRec **out) {
+	*out = nullptr;
+	if (!adac::g_tuning.tile_records || l->ntiles == 0) return ADAC_OK;
+	if (!l->d_tile_recs) ADAC_HIP(hipMalloc((void **)&l->d_tile_recs, l->ntiles * sizeof(adac::TileRec)));
+	if (l->tile_recs_dirty) {
+		ADAC_HIP(adac::launch_expand_tiles(l->ctx->stream, l->type_size, l->d_descs, l->d_tiles, l->ntiles, l->d_tile_recs));
+		l->tile_recs_dirty = false;
+	}
+	*out = l->d_tile_recs;
+	return ADAC_OK;
+}
+
 static adac_status descs_changed(adac_layout *l) {
 	l->groups_dirty = true;
+	l->tile_recs_dirty = true;
 	if (l->d_groups && l->groups_tiles > 0) return expand_groups(l);
 	return ADAC_OK;
 }
@@ -807,7 +825,14 @@ extern "C" adac_status adac_unpack(adac_layout *l, const uint64_t *d_words, void
 	if (!l || ((!d_words || !d_out) && l->total_values)) return ADAC_ERR_INVALID_ARGUMENT;
 	if (!aligned16(d_words) || !aligned16(d_out)) return ADAC_ERR_INVALID_ARGUMENT;
 	ADAC_HIP(hipSetDevice(l->ctx->device));
-	ADAC_HIP(adac::launch_unpack(l->ctx->stream, l->type_size, l->d_descs, l->d_tiles, l->ntiles, d_words, d_out));
+	// (the decode itself keeps the two-hop start — tile entry -> descriptor: with the expanded records it ran 4 - 17 %
+	// SLOWER, same box, interleaved (profiles/r03_tile_records.json); knob tile_records = 3 is that A/B form)
+	const adac::TileRec *recs = nullptr;
+	if (adac::g_tuning.tile_records & 2) {
+		adac_status st = tile_records(l, &recs);
+		if (st != ADAC_OK) return st;
+	}
+	ADAC_HIP(adac::launch_unpack(l->ctx->stream, l->type_size, l->d_descs, l->d_tiles, l->ntiles, d_words, d_out, recs));
 	return ADAC_OK;
 }
 
@@ -1153,7 +1178,10 @@ extern "C" adac_status adac_unpack_selected(adac_layout *l, const uint64_t *d_wo
 	}
 	const uint64_t nblocks = (l->ntiles + 1023) / 1024;
 	uint64_t *d_total = l->d_block_tot + nblocks; // the spare slot after the block totals
-	ADAC_HIP(adac::launch_gather_selected(l->ctx->stream, l->type_size, l->d_descs, l->d_tiles, l->ntiles, d_words,
+	const adac::TileRec *recs = nullptr;
+	adac_status rst = tile_records(l, &recs);
+	if (rst != ADAC_OK) return rst;
+	ADAC_HIP(adac::launch_gather_selected(l->ctx->stream, l->type_size, l->d_descs, l->d_tiles, l->ntiles, d_words, recs,
 	                                      d_bitmap, (l->value_span + 63) / 64, l->d_tile_cnt, l->d_tile_off, l->d_block_tot,
 	                                      d_out, d_out_ids, d_total));
 	if (total_out) return adac_memcpy_d2h(l->ctx, total_out, d_total, sizeof(uint64_t));

@@ -19,6 +19,21 @@ struct TileRef {
 	uint32_t first;
 };
 
+// A tile with its segment's CURRENT descriptor folded in (rebuilt whenever descriptors change, like the scan groups): the
+// gather (k_gather_c) reads ONE 32-byte record before its first data load instead of the dependent chain tile entry ->
+// descriptor — a workgroup's lifetime is a handful of memory round trips, and the bytes a CU keeps in flight per lifetime
+// bound that kernel (+4 - 7 %).  The decode (k_unpack) does NOT take it: measured 4 - 17 % slower with the record, same
+// box, interleaved (profiles/r03_tile_records.json) — as with the scalar descriptor load of round 3's first session.
+struct alignas(32) TileRec {
+	uint64_t word_off; // the segment's first word in the arena
+	uint64_t elem0;    // element index of the tile's first row
+	uint64_t add;      // frame of reference to add back (0 if none)
+	uint32_t first;    // first row of the tile inside the segment
+	uint16_t n;        // rows in the tile (<= 16384)
+	uint8_t width, flags;
+};
+static_assert(sizeof(TileRec) == 32, "device record");
+
 // Work item of the fused scans: `ntiles` consecutive tiles of ONE segment starting at row `first` (static per
 // layout and grouping), and its expansion with the segment's current descriptor (rebuilt whenever descriptors
 // change): a scan workgroup then needs ONE 64-byte load before its first data load instead of the dependent
@@ -90,6 +105,7 @@ struct Tuning {
 	int encode_publish_ahead = 1; // single-pass encode, ordered placement: the parked flow publishes the NEXT footprint before it waits (A/B: 0)
 	int encode_stamps = 0;      // diagnostic: phase time stamps of the single-pass encode (adac_debug_encode_stamps)
 	int grouped_repack = 1;     // A/B: 0 = one tile per workgroup with the 16 KiB row image (the first version)
+	int tile_records = 1;       // expanded 32-byte tile records (TileRec): bit 0 = the gather (k_gather_c: +4 - 7 %), bit 1 = the decode (k_unpack: 4 - 17 % SLOWER, off)
 	int scan_cells = 1;         // fused scans: 1 = results (and shared bitmap words) finished inside the scan kernel through arrival cells, 0 = clearing pass + atomics (+ merge kernel)
 	int gather_compact = 3;     // adac_unpack_selected: 0 = a store per selected row (k_gather), 1 = wave-level compaction + dense stores (k_gather_c), 3 = the same with non-temporal stores
 	int sel_debug = 0;          // diagnostic: selection scan without its flush (1) / without any bitmap emit (2)
@@ -116,7 +132,7 @@ hipError_t launch_pack(hipStream_t s, uint32_t type_size, uint64_t null_bits, co
                        const TileRef *d_tiles, uint64_t ntiles, const void *d_vals, const uint64_t *d_validity,
                        uint64_t *d_words);
 hipError_t launch_unpack(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs, const TileRef *d_tiles,
-                         uint64_t ntiles, const uint64_t *d_words, void *d_out);
+                         uint64_t ntiles, const uint64_t *d_words, void *d_out, const TileRec *d_recs);
 hipError_t launch_unpack_range(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs, RangeArgs range,
                                const uint64_t *d_words, void *d_out);
 hipError_t launch_fetch(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs, const uint64_t *d_words,
@@ -163,11 +179,13 @@ struct ScanGroupList {
 };
 inline uint64_t scan_res_cell_bytes(uint64_t nseg) { return (nseg ? nseg : 1) * 4 * sizeof(unsigned long long); }
 inline uint64_t scan_edge_cell_bytes(uint64_t ngroups) { return (ngroups ? ngroups : 1) * 4 * sizeof(uint32_t); }
+hipError_t launch_expand_tiles(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs, const TileRef *d_tiles,
+                               uint64_t ntiles, TileRec *d_recs);
 hipError_t launch_expand_groups(hipStream_t s, const adac_segment_desc *d_descs, const ScanGroupRef *d_refs,
                                 uint64_t ngroups, ScanGroup *d_groups, uint32_t *d_narrow_idx, uint32_t *d_narrow_count);
 hipError_t launch_gather_selected(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs,
                                   const TileRef *d_tiles, uint64_t ntiles, const uint64_t *d_words,
-                                  const uint64_t *d_bitmap, uint64_t bitmap_words, uint32_t *d_tile_cnt,
+                                  const TileRec *d_recs, const uint64_t *d_bitmap, uint64_t bitmap_words, uint32_t *d_tile_cnt,
                                   uint64_t *d_tile_off, uint64_t *d_block_tot, void *d_out, uint64_t *d_out_ids,
                                   uint64_t *d_total);
 hipError_t launch_scan_sum(hipStream_t s, uint32_t type_size, const ScanGroupList &gl, const uint64_t *d_words,

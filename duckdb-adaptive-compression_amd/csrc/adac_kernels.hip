@@ -119,6 +119,46 @@ __device__ __forceinline__ TileCtx resolve_tile(const adac_segment_desc *__restr
 	return t;
 }
 
+__device__ __forceinline__ uint64_t effective_add(const adac_segment_desc &d);
+
+// An expanded tile record at a wave-uniform address through the scalar unit: eight dwords, taken apart with scalar
+// shifts (gfx9 has no sub-dword scalar load: read field by field the 2- and 1-byte members would come through vector
+// loads).
+__device__ __forceinline__ TileRec load_tile_rec(const TileRec *__restrict__ p) {
+	const uint32_t *__restrict__ q = reinterpret_cast<const uint32_t *>(p);
+	uint32_t w[8];
+#pragma unroll
+	for (int i = 0; i < 8; i++) w[i] = q[i];
+	TileRec r;
+	r.word_off = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+	r.elem0 = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+	r.add = (uint64_t)w[4] | ((uint64_t)w[5] << 32);
+	r.first = w[6];
+	r.n = (uint16_t)(w[7] & 0xffffu);
+	r.width = (uint8_t)((w[7] >> 16) & 0xffu);
+	r.flags = (uint8_t)(w[7] >> 24);
+	return r;
+}
+
+// one thread per tile: the tile entry and its segment's current descriptor -> the tile's record
+__global__ void k_expand_tiles(const adac_segment_desc *__restrict__ descs, const TileRef *__restrict__ tiles,
+                               uint64_t ntiles, uint32_t tile_rows, TileRec *__restrict__ recs) {
+	const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= ntiles) return;
+	const TileRef r = tiles[t];
+	const adac_segment_desc d = descs[r.seg];
+	const uint32_t left = d.count - r.first;
+	TileRec o;
+	o.word_off = d.word_off;
+	o.elem0 = d.val_off + r.first;
+	o.add = effective_add(d);
+	o.first = r.first;
+	o.n = (uint16_t)(left < tile_rows ? left : tile_rows);
+	o.width = d.width;
+	o.flags = d.flags;
+	recs[t] = o;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Stage the packed bits of rows [first, first+n) of a segment into LDS with 16-byte loads.
 // Returns the bit offset (0..127) of row `first` inside the staged image.
@@ -321,12 +361,22 @@ struct StoreSink {
 	}
 };
 
-template <typename U, bool RANGE>
+template <typename U, bool RANGE, bool REC = false>
 __global__ __launch_bounds__(kWorkgroup) void k_unpack(const adac_segment_desc *__restrict__ descs,
                                                        const TileRef *__restrict__ tiles, RangeArgs range,
-                                                       const uint64_t *__restrict__ words, U *__restrict__ out) {
+                                                       const uint64_t *__restrict__ words, U *__restrict__ out,
+                                                       const TileRec *__restrict__ recs = nullptr) {
 	constexpr int TILE = kTileBytes / (int)sizeof(U);
 	__shared__ uint4 lds[kTileBytes / 16 + 2];
+	if constexpr (REC) { // the tile's expanded record: one hop before the data loads
+		const TileRec r = load_tile_rec(recs + blockIdx.x);
+		const uint32_t bit0 = stage_packed(words + r.word_off, r.first, r.n, r.width, lds);
+		__syncthreads();
+		constexpr uint32_t KK = 16 / sizeof(U);
+		StoreSink<U> sink {out + r.elem0, r.n};
+		decode_tile<U>(reinterpret_cast<const uint32_t *>(lds), bit0, r.width, r.add, r.n, (uint32_t)(r.elem0 & (KK - 1)), sink);
+		return;
+	}
 	adac_segment_desc d;
 	uint32_t first, n;
 	uint64_t elem0;
@@ -2359,8 +2409,16 @@ hipError_t launch_repack_g(hipStream_t s, uint32_t type_size, uint64_t null_bits
 	});
 }
 
+hipError_t launch_expand_tiles(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs, const TileRef *d_tiles,
+                               uint64_t ntiles, TileRec *d_recs) {
+	if (ntiles == 0) return hipSuccess;
+	hipLaunchKernelGGL(k_expand_tiles, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, s, d_descs, d_tiles, ntiles,
+	                   (uint32_t)(kTileBytes / type_size), d_recs);
+	return hipGetLastError();
+}
+
 hipError_t launch_unpack(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs, const TileRef *d_tiles,
-                         uint64_t ntiles, const uint64_t *d_words, void *d_out) {
+                         uint64_t ntiles, const uint64_t *d_words, void *d_out, const TileRec *d_recs) {
 	if (ntiles == 0) return hipSuccess;
 	return dispatch_size(type_size, [&](auto tag) {
 		using U = decltype(tag);
@@ -2370,8 +2428,13 @@ hipError_t launch_unpack(hipStream_t s, uint32_t type_size, const adac_segment_d
 			                   d_words, static_cast<U *>(d_out));
 			return hipGetLastError();
 		}
+		if (d_recs) {
+			hipLaunchKernelGGL((k_unpack<U, false, true>), dim3((unsigned)ntiles), dim3(kWorkgroup), 0, s, d_descs, d_tiles,
+			                   RangeArgs {}, d_words, static_cast<U *>(d_out), d_recs);
+			return hipGetLastError();
+		}
 		hipLaunchKernelGGL((k_unpack<U, false>), dim3((unsigned)ntiles), dim3(kWorkgroup), 0, s, d_descs, d_tiles,
-		                   RangeArgs {}, d_words, static_cast<U *>(d_out));
+		                   RangeArgs {}, d_words, static_cast<U *>(d_out), static_cast<const TileRec *>(nullptr));
 		return hipGetLastError();
 	});
 }
@@ -2384,7 +2447,8 @@ hipError_t launch_unpack_range(hipStream_t s, uint32_t type_size, const adac_seg
 		const uint32_t tile = kTileBytes / sizeof(U);
 		const uint32_t nt = (range.count + tile - 1) / tile;
 		hipLaunchKernelGGL((k_unpack<U, true>), dim3(nt), dim3(kWorkgroup), 0, s, d_descs,
-		                   static_cast<const TileRef *>(nullptr), range, d_words, static_cast<U *>(d_out));
+		                   static_cast<const TileRef *>(nullptr), range, d_words, static_cast<U *>(d_out),
+		                   static_cast<const TileRec *>(nullptr));
 		return hipGetLastError();
 	});
 }
@@ -2588,7 +2652,7 @@ hipError_t launch_bp_fetch(hipStream_t s, uint32_t type_size, const uint64_t *d_
 
 hipError_t launch_gather_selected(hipStream_t s, uint32_t type_size, const adac_segment_desc *d_descs,
                                   const TileRef *d_tiles, uint64_t ntiles, const uint64_t *d_words,
-                                  const uint64_t *d_bitmap, uint64_t bitmap_words, uint32_t *d_tile_cnt,
+                                  const TileRec *d_recs, const uint64_t *d_bitmap, uint64_t bitmap_words, uint32_t *d_tile_cnt,
                                   uint64_t *d_tile_off, uint64_t *d_block_tot, void *d_out, uint64_t *d_out_ids,
                                   uint64_t *d_total) {
 	if (ntiles == 0) return hipMemsetAsync(d_total, 0, sizeof(uint64_t), s);
@@ -2603,7 +2667,7 @@ hipError_t launch_gather_selected(hipStream_t s, uint32_t type_size, const adac_
 		hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(kScanBlock), 0, s, d_block_tot, nblocks, d_total);
 		hipLaunchKernelGGL(k_scan_fixup, dim3((unsigned)nblocks), dim3(kScanBlock), 0, s, d_tile_off, ntiles, d_block_tot);
 		if (g_tuning.gather_compact && bitmap_words < (1ull << 31)) { // (32-bit dword indices into the bitmap)
-			hipLaunchKernelGGL(k_gather_c<U>, dim3((unsigned)ntiles), dim3(kWorkgroup), 0, s, d_descs, d_tiles, d_words,
+			hipLaunchKernelGGL(k_gather_c<U>, dim3((unsigned)ntiles), dim3(kWorkgroup), 0, s, d_descs, d_tiles, d_recs, d_words,
 			                   d_bitmap, (uint32_t)(2 * bitmap_words - 1), d_tile_cnt, d_tile_off, static_cast<U *>(d_out), d_out_ids,
 			                   g_tuning.gather_compact & 2);
 		} else {

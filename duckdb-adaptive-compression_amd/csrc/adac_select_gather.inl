@@ -191,6 +191,7 @@ __device__ __forceinline__ uint32_t bitmap_popc(const uint32_t *__restrict__ bm3
 template <typename U>
 __global__ __launch_bounds__(kWorkgroup) void k_gather_c(const adac_segment_desc *__restrict__ descs,
                                                          const TileRef *__restrict__ tiles,
+                                                         const TileRec *__restrict__ recs,
                                                          const uint64_t *__restrict__ words,
                                                          const uint64_t *__restrict__ bitmap, uint32_t last_dword,
                                                          const uint32_t *__restrict__ tile_cnt,
@@ -211,9 +212,20 @@ __global__ __launch_bounds__(kWorkgroup) void k_gather_c(const adac_segment_desc
 	// need anyway — the test costs the other tiles nothing.  A clustered selection (a range of a sorted column) pays
 	// for the tiles it touches only.
 	const uint32_t selected_here = tile_cnt[blockIdx.x];
-	const TileCtx t = resolve_tile<TILE>(descs, tiles);
+	// the tile's geometry: from its expanded record (one hop) or through tile entry -> descriptor (two)
+	struct {
+		uint64_t word_off, elem0, add;
+		uint32_t first, n, width;
+	} t;
+	if (recs) { // uniform
+		const TileRec r = load_tile_rec(recs + blockIdx.x);
+		t.word_off = r.word_off, t.elem0 = r.elem0, t.add = r.add, t.first = r.first, t.n = r.n, t.width = r.width;
+	} else {
+		const TileCtx c = resolve_tile<TILE>(descs, tiles);
+		t.word_off = c.d.word_off, t.elem0 = c.elem0, t.add = effective_add(c.d), t.first = c.first, t.n = c.n, t.width = c.d.width;
+	}
 	if (selected_here == 0u) return;
-	const uint32_t bit0 = stage_packed(words + t.d.word_off, t.first, t.n, t.d.width, lds);
+	const uint32_t bit0 = stage_packed(words + t.word_off, t.first, t.n, t.width, lds);
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	const uint32_t *__restrict__ bm32 = reinterpret_cast<const uint32_t *>(bitmap);
 	// selected rows before each run of the tile: inclusive scan over the lanes' words
@@ -369,5 +381,5 @@ __global__ __launch_bounds__(kWorkgroup) void k_gather_c(const adac_segment_desc
 		}
 		__builtin_amdgcn_wave_barrier();
 	};
-	decode_tile<U, true>(reinterpret_cast<const uint32_t *>(lds), bit0, t.d.width, effective_add(t.d), t.n, 0u, sink);
+	decode_tile<U, true>(reinterpret_cast<const uint32_t *>(lds), bit0, t.width, t.add, t.n, 0u, sink);
 }

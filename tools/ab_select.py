@@ -80,6 +80,8 @@ def main():
             vmask = rng.random(rows) < valid_frac
             vb = np.packbits(vmask, bitorder="little")
             d_valid = ctx.upload(np.concatenate([vb, np.zeros((-len(vb)) % 8 + 8, np.uint8)]).view(np.uint64))
+        t_unp = [[] for _ in settings]
+        d_dec = ctx.alloc(rows * dtype.itemsize + 64)
         t_sum = [[] for _ in settings]
         t_cnt = [[] for _ in settings]
         wide = np.int64 if dtype.kind == "i" else np.uint64
@@ -110,6 +112,8 @@ def main():
                     assert np.array_equal(d_cnt.download(np.uint64, len(counts)), exp_sums), (case, st, "sums")
                     lay.scan_count_between(d_words, 0, hi, d_cnt)
                     assert np.array_equal(d_cnt.download(np.uint64, len(counts)), exp_cnts), (case, st, "counts")
+                    lay.unpack(d_words, d_dec)
+                    assert np.array_equal(d_dec.download(dtype, rows), vals), (case, st, "decode")
                     if d_valid is not None:
                         ev = np.add.reduceat(np.where(vmask, vals, 0).astype(wide), starts[:-1]).astype(np.uint64)
                         lay.scan_sum(d_words, d_cnt, d_valid)
@@ -137,6 +141,10 @@ def main():
                     for _ in range(reps):
                         lay.unpack_selected(d_words, d_cbm, d_out, d_ids, False)
                     t_clu[i].append(ctx.timer_stop() / reps)
+                ctx.timer_start()
+                for _ in range(reps):
+                    lay.unpack(d_words, d_dec)
+                t_unp[i].append(ctx.timer_stop() / reps)
                 ctx.timer_start()
                 for _ in range(reps):
                     lay.scan_sum(d_words, d_cnt)
@@ -169,10 +177,12 @@ def main():
                                     "select_read_GBps": packed / ms_s / 1e6,
                                     "sum_ms": float(np.median(t_sum[i])), "sum_read_GBps": packed / float(np.median(t_sum[i])) / 1e6,
                                     "count_ms": float(np.median(t_cnt[i])), "count_read_GBps": packed / float(np.median(t_cnt[i])) / 1e6,
+                                    "unpack_ms": float(np.median(t_unp[i])),
+                                    "unpack_total_GBps": (packed + rows * dtype.itemsize) / float(np.median(t_unp[i])) / 1e6,
                                     "gather_ms": ms_g, "gather_min_ms": float(min(t_gat[i])),
                                     "gather_traffic_GBps": gbytes / ms_g / 1e6})
         out["cases"].append(rec)
-        del d_words, d_bm, d_cnt, d_out, d_ids, lay
+        del d_words, d_bm, d_cnt, d_out, d_ids, d_dec, lay
     print(json.dumps(out, indent=1))
 
 

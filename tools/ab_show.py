@@ -14,6 +14,8 @@ for f in sys.argv[1:]:
                 print("    %-40s sel %.4f (%4.0f) sum %.4f (%4.0f) cnt %.4f (%4.0f) gather %.4f (%4.0f GB/s)" % (
                     k, s["select_ms"], s["select_read_GBps"], s.get("sum_ms", 0), s.get("sum_read_GBps", 0),
                     s.get("count_ms", 0), s.get("count_read_GBps", 0), s["gather_ms"], s["gather_traffic_GBps"]))
+                if "unpack_ms" in s:
+                    print("    %-40s unpack %.4f ms (%4.0f GB/s of read + written bytes)" % ("", s["unpack_ms"], s["unpack_total_GBps"]))
                 if "clustered_gather_ms" in s:
                     print("    %-40s clustered %.0f %%: gather %.4f ms" % ("", 100 * s["clustered_fraction"], s["clustered_gather_ms"]))
                 if "masked_sum_ms" in s:
