@@ -316,3 +316,42 @@ def test_scans_finish_their_results_inside_the_kernel(adac, oracle, gpu_ctx, dty
         adac.set_tuning("scan_cells", 1)
         adac.set_tuning("sel_debug", 0)
         adac.set_tuning("scan_tiles_per_wg", 0)
+
+
+@pytest.mark.parametrize("dtype", [np.uint64, np.uint32])
+def test_unpack_selected_follows_the_descriptors_of_a_re_encoded_layout(adac, oracle, gpu_ctx, dtype):
+    """The gather reads expanded tile records (the tile with its segment's descriptor folded in, round 3): they must be
+    rebuilt whenever the descriptors change — a second adac_encode of the same layout with other widths and arena
+    offsets, a third through the three kernels, and adac_layout_set_descs — and both the record form and the
+    tile entry -> descriptor form (knob tile_records = 0) must agree, clustered and scattered selections alike."""
+    dtype = np.dtype(dtype)
+    rng = np.random.default_rng(31 + dtype.itemsize)
+    tile = adac.tile_values(dtype)
+    counts = np.array([3 * tile + 5, tile, 7, 2 * tile - 1, 5 * tile + 100], dtype=np.uint32)
+    n = int(counts.sum())
+    lay = adac.Layout(gpu_ctx, dtype, counts)
+    d_words = gpu_ctx.alloc(lay.max_arena_words * 8 + 64).zero()
+    d_out = gpu_ctx.alloc(n * dtype.itemsize + 64)
+    d_ids = gpu_ctx.alloc(n * 8 + 64)
+    sels = [rng.random(n) < 0.4, np.zeros(n, dtype=bool)]
+    sels[1][n // 3:n // 3 + 2 * tile + 17] = True      # clustered: most tiles hold no selected row
+    try:
+        for step, bits in enumerate((5, 27, 13, 9)):
+            vals = np.concatenate([make_values(rng, dtype, int(c), bits + (i % 3)) for i, c in enumerate(counts)])
+            d_vals = gpu_ctx.upload(vals)
+            adac.set_tuning("single_pass_encode", 0 if step == 2 else 1)
+            lay.encode(d_vals, d_words, None, adac.RULE_APPEND, False)
+            if step == 3:  # the same descriptors handed back through adac_layout_set_descs
+                lay.set_descs(lay.get_descs())
+            for sel in sels:
+                d_bm = gpu_ctx.upload(pack_mask(sel, n)[:(n + 63) // 64])
+                keep = np.flatnonzero(sel)
+                for records in (1, 0, 1):
+                    adac.set_tuning("tile_records", records)
+                    got = lay.unpack_selected(d_words, d_bm, d_out, d_ids)
+                    assert got == len(keep), (step, records)
+                    assert np.array_equal(d_out.download(dtype, max(got, 1))[:got], vals[keep]), (step, records)
+                    assert np.array_equal(d_ids.download(np.uint64, max(got, 1))[:got], keep.astype(np.uint64)), (step, records)
+    finally:
+        adac.set_tuning("tile_records", 1)
+        adac.set_tuning("single_pass_encode", 1)
