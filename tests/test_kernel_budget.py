@@ -61,6 +61,6 @@ def test_common_fused_scan_stays_thin(table, utype, op):
 
 @pytest.mark.parametrize("utype", ["u64", "u32", "u16", "u8"])
 def test_decode_kernel_stays_thin(table, utype):
-    for k in ("k_unpack<%s,false>" % utype, "k_unpack_jobs<%s>" % utype):
+    for k in ("k_unpack<%s,false,false>" % utype, "k_unpack_jobs<%s>" % utype):
         r = table[k]
         assert r["occupancy"] == 8 and r["vgpr_spills"] == 0 and r["scratch"] == 0, (k, r)
