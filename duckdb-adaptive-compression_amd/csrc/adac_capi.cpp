@@ -344,6 +344,7 @@ extern "C" int adac_set_tuning(const char *name, int value) {
 	else if (n == "single_pass_encode") adac::g_tuning.single_pass_encode = value;
 	else if (n == "encode_stamps") adac::g_tuning.encode_stamps = value;
 	else if (n == "encode_placement") adac::g_tuning.encode_placement = value;
+	else if (n == "encode_big_image") adac::g_tuning.encode_big_image = value;
 	else if (n == "encode_publish_ahead") adac::g_tuning.encode_publish_ahead = value;
 	else if (n == "scan_cells") adac::g_tuning.scan_cells = value;
 	else if (n == "tile_records") adac::g_tuning.tile_records = value;

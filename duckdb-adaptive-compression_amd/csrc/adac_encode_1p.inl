@@ -163,7 +163,19 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 	uint4 *const stage = reinterpret_cast<uint4 *>(pool);
 	unsigned long long *const img = reinterpret_cast<unsigned long long *>(pool + kStageBytes);
 	uint32_t *const park = reinterpret_cast<uint32_t *>(pool);
+	// the whole pool as ONE image (round 3, "big image"): a segment whose packed output fits it is packed into LDS in one
+	// go, the next segment is loaded and analysed, and only then is the arena offset asked for (publish-ahead, see `pend`)
+	constexpr uint32_t kPoolWords = (kStageBytes + kImgBytes) / 8u - 4u;
+	unsigned long long *const pool64 = reinterpret_cast<unsigned long long *>(pool);
+	struct ImagePending { // the segment whose image waits in the pool (written by thread 0, read by everybody: uniform)
+		uint64_t mn, mx, stored_min, footprint;
+		uint32_t seg, w, flags, nwords;
+	};
+	__shared__ ImagePending s_ipend;
+	bool ipend_active = false; // (uniform)
 	bool img_dirty = false;   // the parking area was used since the image was last all zero (uniform)
+	bool stage_dirty = true;  // the stage region holds prefetched rows, or was never cleared (uniform)
+	bool staged = false;      // the next segment's first rounds were prefetched into the stage this iteration (uniform)
 	bool next_loaded = false; // the next segment's loads were issued by the parked flow (uniform)
 	__shared__ uint64_t pmin[kEncThreads / 64], pmax[kEncThreads / 64];
 	__shared__ uint64_t s_word_off;
@@ -470,6 +482,34 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 		pend.active = false;
 		lds_barrier(); // the parking area is free again before this segment's pack may use the pool
 	}
+	// ... or the segment whose whole image waits in the pool: its offset, its words out of LDS (zeroed as they leave)
+	if (ipend_active) { // uniform
+		Analysis pa;
+		pa.mn = uniform64(s_ipend.mn), pa.mx = uniform64(s_ipend.mx), pa.stored_min = uniform64(s_ipend.stored_min);
+		pa.footprint = uniform64(s_ipend.footprint);
+		pa.w = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ipend.w);
+		pa.flags = (uint8_t)__builtin_amdgcn_readfirstlane((int)s_ipend.flags);
+		const uint32_t pseg = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ipend.seg);
+		const uint32_t pwords = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ipend.nwords);
+		unsigned long long *__restrict__ pout = place_segment(pa, pseg, false);
+		for (uint32_t i = 2u * tid; i < pwords; i += 2u * kEncThreads) {
+			const unsigned long long v0 = pool64[i], v1 = pool64[i + 1];
+			pool64[i] = 0ull;
+			pool64[i + 1] = 0ull;
+			if (i + 1 < pwords) {
+				uint4 o;
+				o.x = (uint32_t)v0;
+				o.y = (uint32_t)(v0 >> 32);
+				o.z = (uint32_t)v1;
+				o.w = (uint32_t)(v1 >> 32);
+				nt_store16(pout + i, o);
+			} else {
+				pout[i] = v0;
+			}
+		}
+		ipend_active = false;
+		lds_barrier(); // the pool is all zero again before this segment's pack may use it
+	}
 	do { // phase 4 (left with `break` where the one-segment form returned)
 	// whole-dword strings (4a below)?  With at most two dwords per chunk the strings are PARKED in LDS, the next
 	// segment's loads are issued into the freed registers, and only then is the arena offset asked for: the look-back
@@ -477,7 +517,20 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 	const bool whole_dwords = n != 0u && !validity && ((K * w) & 31u) == 0u && ((align * w) & 31u) == 0u &&
 	                          (w <= 32u || w == type_bits);
 	const bool parked = whole_dwords && K * w <= 64u;
-	if (!parked) prefetch(nxt);
+	// big image: every other width of a segment whose packed words fit the pool, when another segment follows and the
+	// placement is ordered (bit 2 of `placement`: knob encode_big_image)
+	const uint32_t seg_words = (uint32_t)(((uint64_t)n * w + 63u) >> 6);
+	// (by WIDTH, not by this segment's size: a full segment of kEncRounds rounds at this width must fit, so that the
+	// segments of a column take the same flow as long as their width stays — a column whose 65534-row segments do not
+	// fit while its shorter ones do alternates between the flows and ran 2x slower: u32 w = 20, profiles/r03_encode_big_image.json)
+	const bool bigimg = !whole_dwords && n != 0u && !validity && w <= 32u && seg_words + 2u <= kPoolWords &&
+	                    (uint64_t)kEncRounds * ROUND_ROWS * w + 128u <= (uint64_t)kPoolWords * 64u &&
+	                    nxt.seg < nseg && !first_come && (placement & 4);
+	staged = !parked && !bigimg;
+	if (staged) {
+		prefetch(nxt);
+		stage_dirty = stage_dirty || nxt.seg < nseg;
+	}
 	if (n == 0) {
 		place(true);
 		break;
@@ -534,6 +587,7 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 				}
 			}
 			img_dirty = true;
+			stage_dirty = true;
 			// ... the next segment's rows start travelling into the freed registers (wave 0 later: its look-back loads
 			// would queue behind them) ...
 			auto load_next = [&]() {
@@ -634,6 +688,14 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 		break;
 	}
 
+	unsigned long long *const imgp = bigimg ? pool64 : img; // (uniform)
+	if (bigimg && (img_dirty || stage_dirty)) { // uniform: the pool holds prefetched rows or parked strings
+		lds_barrier();
+		for (uint32_t i = tid; i < kPoolWords + 4; i += kEncThreads) pool64[i] = 0ull;
+		lds_barrier();
+		img_dirty = false;
+		stage_dirty = false;
+	}
 	if (img_dirty) { // uniform: a parked segment wrote over the image since it was last cleared
 		lds_barrier();
 		for (uint32_t i = tid; i < kEncImageWords + 4; i += kEncThreads) img[i] = 0ull;
@@ -642,6 +704,7 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 	}
 	uint32_t rps = (kEncImageWords * 64u) / (ROUND_ROWS * w); // whole rounds per stage
 	rps = rps < 1u ? 1u : rps;
+	if (bigimg) rps = (uint32_t)kEncRounds; // the whole segment is ONE stage
 	uint32_t stage_lo = 0; // first row of the current stage (a multiple of ROUND_ROWS)
 
 	// rows [lo, hi) of chunk (row0 .. row0 + K) -> the stage image
@@ -668,7 +731,7 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 			// negative, so such a chunk goes row by row below
 			if (row0 >= (int32_t)stage_lo) {
 				const Str128 str = chunk_string32<U>(v, (uint32_t)sub, (uint32_t)wmask, w);
-				image_or32(reinterpret_cast<uint32_t *>(img), ((uint32_t)row0 - stage_lo) * w, str, (uint32_t)K * w);
+				image_or32(reinterpret_cast<uint32_t *>(imgp), ((uint32_t)row0 - stage_lo) * w, str, (uint32_t)K * w);
 				return;
 			}
 		}
@@ -678,12 +741,12 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 		if (inside) {
 			uint64_t s_lo, s_hi;
 			concat_fields<U>(f, w, s_lo, s_hi);
-			image_or(img, ((uint32_t)row0 - stage_lo) * w, s_lo, s_hi);
+			image_or(imgp, ((uint32_t)row0 - stage_lo) * w, s_lo, s_hi);
 		} else {
 #pragma unroll
 			for (int j = 0; j < K; j++) {
 				const int32_t row = row0 + j;
-				if (row >= (int32_t)lo && row < (int32_t)hi) image_or(img, ((uint32_t)row - stage_lo) * w, (uint64_t)f[j], 0ull);
+				if (row >= (int32_t)lo && row < (int32_t)hi) image_or(imgp, ((uint32_t)row - stage_lo) * w, (uint64_t)f[j], 0ull);
 			}
 		}
 	};
@@ -733,12 +796,20 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 			U v[K];
 			__builtin_memcpy(v, &q[r], 16);
 			const Str128 str = chunk_string32<U>(v, (uint32_t)sub, (uint32_t)wmask, w);
-			image_or32(reinterpret_cast<uint32_t *>(img), p_thread + (round_row - stage_lo) * w, str, (uint32_t)K * w);
+			image_or32(reinterpret_cast<uint32_t *>(imgp), p_thread + (round_row - stage_lo) * w, str, (uint32_t)K * w);
 		} else if (c < nchunks) {
 			emit(q[r], c, stage_lo, stage_hi < n ? stage_hi : n);
 		}
 	}
-	flush(n);
+	if (bigimg) { // the image stays in the pool: the next segment is loaded, analysed and published first
+		if (tid == 0) {
+			s_ipend.mn = mn, s_ipend.mx = mx, s_ipend.stored_min = stored_min, s_ipend.footprint = footprint;
+			s_ipend.seg = seg, s_ipend.w = w, s_ipend.flags = flags, s_ipend.nwords = seg_words;
+		}
+		ipend_active = true;
+	} else {
+		flush(n);
+	}
 	} while (0);
 	ADAC_STAMP(4);
 
@@ -751,9 +822,17 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 		continue;
 	}
 	if (tid == 0) next_ticket = atomicAdd(ticket, 1u);
+	if (staged) { // uniform
 #pragma unroll
-	for (int r = 0; r < kEncPrefetch; r++) q[r] = stage[(uint32_t)r * kEncThreads + tid];
-	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the staged chunks are in registers before LDS-DMA may overwrite them
+		for (int r = 0; r < kEncPrefetch; r++) q[r] = stage[(uint32_t)r * kEncThreads + tid];
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the staged chunks are in registers before LDS-DMA may overwrite them
+	} else { // (big image: nothing was prefetched, the pool holds the image)
+#pragma unroll
+		for (int r = 0; r < kEncPrefetch; r++) {
+			const uint32_t c = (uint32_t)r * kEncThreads + tid;
+			q[r] = cur.base16[c < cur.last_chunk ? c : cur.last_chunk];
+		}
+	}
 #pragma unroll
 	for (int r = kEncPrefetch; r < kEncRounds; r++) {
 		const uint32_t c = (uint32_t)r * kEncThreads + tid;

@@ -102,6 +102,7 @@ struct Tuning {
 	int group_sum_wide = 0;     // A/B: adac_scan_group_sum always in 64-bit arithmetic
 	int group_sum_rw = 1;       // A/B: 0 = adac_scan_group_sum without the register-walk kernel (k_group_sum only)
 	int encode_placement = 0;   // single-pass encode: 0 = arena order is segment order (look-back), 1 = order of completion
+	int encode_big_image = 1;   // single-pass encode, ordered placement: a segment whose packed words fit the LDS pool is packed there whole and publishes the NEXT footprint before it waits (A/B: 0)
 	int encode_publish_ahead = 1; // single-pass encode, ordered placement: the parked flow publishes the NEXT footprint before it waits (A/B: 0)
 	int encode_stamps = 0;      // diagnostic: phase time stamps of the single-pass encode (adac_debug_encode_stamps)
 	int grouped_repack = 1;     // A/B: 0 = one tile per workgroup with the 16 KiB row image (the first version)

@@ -2324,7 +2324,8 @@ hipError_t launch_encode_1p(hipStream_t s, uint32_t type_size, bool sign_extend,
 		hipLaunchKernelGGL(k_encode_1p<U>, dim3(grid), dim3(kEncThreads), 0, s, d_descs, d_descs, (uint32_t)nseg, d_minmax,
 		                   static_cast<const U *>(d_vals), d_validity, sign_extend ? 1 : 0, null_bits, rule, pad_to_byte,
 		                   state, reinterpret_cast<uint32_t *>(state + nseg), d_words, g_tuning.encode_stamps,
-		                   (g_tuning.encode_placement & 1) | (g_tuning.encode_publish_ahead ? 2 : 0));
+		                   (g_tuning.encode_placement & 1) | (g_tuning.encode_publish_ahead ? 2 : 0) |
+		                       (g_tuning.encode_big_image ? 4 : 0));
 		return hipGetLastError();
 	});
 }

@@ -683,6 +683,15 @@ def test_single_pass_encode_mixes_its_flows(adac, oracle, gpu_ctx, dtype):
             for padded in (False, True):
                 run_encode_decode(adac, oracle, gpu_ctx, dtype, counts, seg_vals, rule, padded, val_offs=val_offs)
         lay1, w1, _, d1, _ = run_encode_decode(adac, oracle, gpu_ctx, dtype, counts, seg_vals, val_offs=val_offs)
+        # (round 3) the big-image flow — a segment packed whole into the LDS pool, its stores deferred until the next
+        # segment is analysed — and the deferred parked flow are on by default above; without them: the same bytes
+        for knob in ("encode_big_image", "encode_publish_ahead"):
+            adac.set_tuning(knob, 0)
+            try:
+                _, _, _, d0, _ = run_encode_decode(adac, oracle, gpu_ctx, dtype, counts, seg_vals, val_offs=val_offs)
+            finally:
+                adac.set_tuning(knob, 1)
+            assert d0.tobytes() == d1.tobytes(), knob
     finally:
         adac.set_tuning("single_pass_encode", 1)
     # the three-kernel form on the same column: identical descriptors and arena; and the default choice
