@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off soak: the differential fuzz of tests/test_gpu_fuzz.py over many more seeds than the suite carries.
-usage: python tools/soak_fuzz.py [first_seed] [count]"""
+usage: python tools/soak_fuzz.py [first_seed] [count]   (ADAC_TUNING=knob=value,... sets tuning knobs first)"""
 import importlib
 import os
 import sys
@@ -17,6 +17,9 @@ import test_gpu_fuzz as fz  # noqa: E402
 adac = importlib.import_module("duckdb-adaptive-compression_amd")
 adac.build()
 orc.build()
+for kv in filter(None, os.environ.get("ADAC_TUNING", "").split(",")):   # e.g. ADAC_TUNING=single_pass_encode=2
+    k, v = kv.split("=")
+    adac.set_tuning(k, int(v))
 ctx = adac.Context(0)
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
