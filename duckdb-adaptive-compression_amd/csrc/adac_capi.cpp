@@ -62,6 +62,9 @@ struct adac_layout {
 	void *d_scan_state = nullptr; // its look-back words + ticket (allocated on first use)
 	bool dense_values = true; // segments back to back from element 0: no element index between them is unowned
 	bool has_empty_segments = false; // a segment without rows has no scan group: its result is cleared, not stored
+	// the widest segment among the descriptors that last passed through the host (adac_layout_get_descs / _set_descs), 0 =
+	// never seen: a HINT for adac_encode's choice of form on 4-byte columns (performance only: every form is correct)
+	uint32_t hint_max_width = 0;
 	std::vector<uint32_t> counts;
 	std::vector<uint64_t> val_offs;
 	adac_segment_desc *d_descs = nullptr;
@@ -96,6 +99,7 @@ struct adac_layout {
 };
 
 static adac_status descs_changed(adac_layout *l);
+static void note_widths(adac_layout *l, const adac_segment_desc *descs);
 static adac_status ensure_scan_groups(adac_layout *l);
 
 // ------------------------------------------------------------------------------------------------
@@ -616,12 +620,23 @@ extern "C" adac_status adac_layout_set_descs(adac_layout *l, const adac_segment_
 		                        l->ctx->stream));
 		ADAC_HIP(hipStreamSynchronize(l->ctx->stream));
 	}
+	note_widths(l, descs);
 	return descs_changed(l);
+}
+
+static void note_widths(adac_layout *l, const adac_segment_desc *descs) {
+	uint32_t mx = 0;
+	for (uint64_t s = 0; s < l->nseg; s++) {
+		if (descs[s].count && descs[s].width > mx) mx = descs[s].width;
+	}
+	l->hint_max_width = mx;
 }
 
 extern "C" adac_status adac_layout_get_descs(adac_layout *l, adac_segment_desc *descs) {
 	if (!l || (l->nseg && !descs)) return ADAC_ERR_INVALID_ARGUMENT;
-	return adac_memcpy_d2h(l->ctx, descs, l->d_descs, l->nseg * sizeof(adac_segment_desc));
+	adac_status st = adac_memcpy_d2h(l->ctx, descs, l->d_descs, l->nseg * sizeof(adac_segment_desc));
+	if (st == ADAC_OK) note_widths(l, descs);
+	return st;
 }
 
 extern "C" adac_status adac_layout_get_minmax(adac_layout *l, uint64_t *minmax) {
@@ -747,7 +762,13 @@ extern "C" adac_status adac_encode(adac_layout *l, const void *d_vals, const uin
 	//   2- / 1-byte types  three kernels (the single-pass instantiations are instruction-bound / spill:
 	//                      profiles/r03_encode_small_types.json).
 	// Knob "single_pass_encode": 0 never, 1 by this table, 2 always.
-	const bool one_pass_pays = l && (l->type_size == 8 || (l->type_size == 4 && adac::g_tuning.encode_placement == 1));
+	// 4-byte types under ordered placement: the single pass wins (8 - 14 %) while a full segment's packed words fit the LDS
+	// pool — widths up to 17 (the big image publishes ahead) — and loses (21 - 36 %) above; the widths are not known before
+	// the analysis, so the choice follows the widest segment the host last SAW of this layout (a re-encode of a column, or
+	// the adaptive policy's repeated compaction), and stays with the three kernels when it saw none
+	// (profiles/r03_encode_big_image.json)
+	const bool narrow_hint = l && l->hint_max_width != 0 && l->hint_max_width <= 17;
+	const bool one_pass_pays = l && (l->type_size == 8 || (l->type_size == 4 && (adac::g_tuning.encode_placement == 1 || narrow_hint)));
 	if (l && adac::g_tuning.single_pass_encode && l->single_pass_ok &&
 	    (one_pass_pays || adac::g_tuning.single_pass_encode > 1)) {
 		// one kernel, the raw column read once (adac_encode_1p.inl); same descriptors, min/max and words

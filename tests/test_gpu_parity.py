@@ -734,3 +734,42 @@ def test_single_pass_encode_mixes_its_flows(adac, oracle, gpu_ctx, dtype):
     got = d_out.download(dtype, layf.value_span)
     for v, o in zip(seg_vals, offs):
         assert np.array_equal(got[o:o + len(v)], v)
+
+
+def test_encode_form_follows_the_widths_the_host_last_saw(adac, oracle, gpu_ctx):
+    """adac_encode on a 4-byte column with ordered placement: the three kernels while the host has not seen the layout's
+    descriptors, the single pass once it has and the widest segment needs at most 17 bits (the big image publishes
+    ahead there: profiles/r03_encode_big_image.json).  A hint, not a contract: whatever form runs, descriptors, min/max
+    and every packed word are the same — checked across the switch, for a narrow column, a wide one and one whose
+    widths change between the two encodes."""
+    dtype = np.dtype(np.uint32)
+    rng = np.random.default_rng(77)
+    tile = adac.tile_values(dtype)
+    counts = np.array([5 * tile + 3, 16 * tile - 2, 7, 16 * tile - 2, 3 * tile], dtype=np.uint32)
+    n = int(counts.sum())
+    lay = adac.Layout(gpu_ctx, dtype, counts)
+    d_words = gpu_ctx.alloc(lay.max_arena_words * 8 + 64)
+    for bits_first, bits_second in ((13, 13), (24, 24), (9, 22), (22, 9)):
+        seen = []
+        for bits in (bits_first, bits_second, bits_second):
+            vals = np.concatenate([make_values(rng, dtype, int(c), bits) for c in counts])
+            d_vals = gpu_ctx.upload(vals)
+            d_words.zero()
+            lay.encode(d_vals, d_words, None, adac.RULE_APPEND, False)   # the form follows the hint of the last get_descs
+            descs = lay.get_descs()                                       # ... which this call refreshes
+            words = d_words.download(np.uint64, lay.max_arena_words)
+            adac.set_tuning("single_pass_encode", 0)                      # the three kernels, whatever the hint
+            try:
+                d_words.zero()
+                lay.encode(d_vals, d_words, None, adac.RULE_APPEND, False)
+                descs3 = lay.get_descs()
+                words3 = d_words.download(np.uint64, lay.max_arena_words)
+            finally:
+                adac.set_tuning("single_pass_encode", 1)
+            assert descs.tobytes() == descs3.tobytes(), (bits_first, bits_second, bits)
+            assert np.array_equal(words, words3), (bits_first, bits_second, bits)
+            d_out = gpu_ctx.alloc(n * 4 + 64)
+            lay.unpack(d_words, d_out)
+            assert np.array_equal(d_out.download(dtype, n), vals)
+            seen.append(sorted(set(descs["width"].tolist())))
+        assert max(seen[-1]) <= bits_second + 1
