@@ -516,16 +516,22 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 	// wait overlaps those loads instead of idling the CU's memory pipe.  Other segments prefetch through LDS-DMA.
 	const bool whole_dwords = n != 0u && !validity && ((K * w) & 31u) == 0u && ((align * w) & 31u) == 0u &&
 	                          (w <= 32u || w == type_bits);
-	const bool parked = whole_dwords && K * w <= 64u;
+	bool parked = whole_dwords && K * w <= 64u;
 	// big image: every other width of a segment whose packed words fit the pool, when another segment follows and the
 	// placement is ordered (bit 2 of `placement`: knob encode_big_image)
 	const uint32_t seg_words = (uint32_t)(((uint64_t)n * w + 63u) >> 6);
 	// (by WIDTH, not by this segment's size: a full segment of kEncRounds rounds at this width must fit, so that the
 	// segments of a column take the same flow as long as their width stays — a column whose 65534-row segments do not
 	// fit while its shorter ones do alternates between the flows and ran 2x slower: u32 w = 20, profiles/r03_encode_big_image.json)
-	const bool bigimg = !whole_dwords && n != 0u && !validity && w <= 32u && seg_words + 2u <= kPoolWords &&
+	// The ONE-dword strings of the parked flow (K w = 32: u64 w = 16, u32 w = 8) take the big image too: at those widths
+	// a segment parks only at some placements in the value buffer (a multiple of 32 bits before its first row), so a column
+	// alternated between the parked and the staged flow — 0.480 -> 0.444 ms at u64 w = 16, 0.583 -> 0.569 at u32 w = 8.
+	// Two-dword strings (u64 w = 32, u32 w = 16) stay parked: 0.248 / 0.305 against 0.252 / 0.310 ms through the image.
+	const bool bigimg = (!whole_dwords || (parked && K * w == 32u)) && n != 0u && !validity && w <= 32u && seg_words + 2u <= kPoolWords &&
 	                    (uint64_t)kEncRounds * ROUND_ROWS * w + 128u <= (uint64_t)kPoolWords * 64u &&
 	                    nxt.seg < nseg && !first_come && (placement & 4);
+	if (bigimg) parked = false;
+	const bool whole_dwords_now = whole_dwords && !bigimg;
 	staged = !parked && !bigimg;
 	if (staged) {
 		prefetch(nxt);
@@ -546,7 +552,7 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_1p(adac_segment_desc *__
 	// segment's first one fill whole dwords too, thread t's string IS dwords [c nd - skip, c nd - skip + nd) of the
 	// segment: one coalesced store per chunk, no LDS image, no barrier, and the stores of a round overlap the next
 	// round's arithmetic.  The image path below cost ~20 vector instructions + 3 ds_or per chunk plus the copy-out.
- 	if (whole_dwords) {
+ 	if (whole_dwords_now) {
 		const uint32_t nd = (K * w) >> 5;                                              // dwords per chunk: 1..4
 		const uint32_t skip = (align * w) >> 5;                                        // dwords of the rows before row 0
 		const uint32_t nd_total = 2u * (uint32_t)(((uint64_t)n * w + 63u) >> 6);       // the segment's words, in dwords
